@@ -1,0 +1,126 @@
+/*
+ * rt_mi355x.h — C ABI of librt_mi355x.so: the per-pixel render path of Aandreba/raytracing on MI355X (gfx950).
+ *
+ * The reference (Rust, /root/reference/src) has no FFI or plugin interface; this boundary is new and sits at the
+ * seam `Renderer::render` (renderer.rs:32-82) / `Framebuffer::update` (display.rs:74-105): everything between
+ * "scene slices + camera + W x H" and "bytes in Framebuffer.pixels".  Each entry point cites what it replaces.
+ * INTEGRATION.md shows the Rust `extern "C"` block and the `Renderer::render` body a maintainer would add.
+ *
+ * Conventions
+ *   - every function returns RT_OK (0) or a negative RT_ERR_*; no exception crosses the boundary;
+ *   - a rt_ctx is bound to ONE device (one process per GPU; multi-GPU = one ctx per rank, row bands, see
+ *     rt_render_rows*) and is NOT thread-safe (mirrors `&mut self` of Renderer::render, renderer.rs:32);
+ *   - arrays passed in are borrowed for the duration of the call only;
+ *   - there is no CPU fallback: without a usable gfx950 device rt_ctx_create fails with RT_ERR_NO_DEVICE.
+ */
+#ifndef RT_MI355X_H
+#define RT_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK 0
+#define RT_ERR_INVALID (-1)   /* bad argument (null pointer, depth == 0, unknown kind, rows out of range ...) */
+#define RT_ERR_NO_DEVICE (-2) /* no HIP device / device id out of range / not gfx950 */
+#define RT_ERR_HIP (-3)       /* a HIP runtime call failed; text in rt_last_error */
+#define RT_ERR_NO_SCENE (-4)  /* rt_render* before rt_scene_upload */
+#define RT_ERR_TOO_LARGE (-5) /* size beyond a documented limit */
+
+/* object kinds — object/mod.rs:7-10 (trait Object); only Sphere exists in the reference (object/sphere.rs) */
+#define RT_SPHERE 0u
+/* light kinds — light/mod.rs:8-10 (trait Light): light/point.rs, light/ambient.rs */
+#define RT_POINT 0u
+#define RT_AMBIENT 1u
+
+/* rt_render* flags */
+#define RT_SHADOWS 1u  /* EXTENSION (no reference counterpart): point lights are occluded by elements, see DESIGN.md */
+#define RT_OUT_RGB8 2u /* write 3 B/pixel exactly like Framebuffer.pixels (display.rs:16-20,50-57); default RGBA8, A=255 */
+
+/* shadow-ray acceptance window of the RT_SHADOWS extension: occluded iff RT_SHADOW_EPS < t < distance(light) */
+#define RT_SHADOW_EPS 1.0e-3f
+
+/*
+ * Flattened `&[Element<DynObject>]` (renderer.rs:37, element.rs:10-19, object/sphere.rs:6-9), SoA, element order
+ * preserved (ties: lowest index wins, renderer.rs:49-53).  Only Material.reflectiveness is read by the reference
+ * (renderer.rs:66), so only it crosses the boundary.
+ */
+typedef struct rt_objects {
+    int32_t n;
+    const uint8_t* kind; /* n entries, RT_SPHERE; NULL => all spheres */
+    const float *cx, *cy, *cz, *radius;
+    const float *refl_r, *refl_g, *refl_b;
+} rt_objects;
+
+/* Flattened `&[DynLight]` (renderer.rs:38, light/point.rs:5-9, light/ambient.rs:5-7), list order preserved (renderer.rs:60-64). */
+typedef struct rt_lights {
+    int32_t n;
+    const uint8_t* kind; /* n entries, RT_POINT / RT_AMBIENT; NULL => all point lights */
+    const float *px, *py, *pz; /* ignored for RT_AMBIENT */
+    const float *cr, *cg, *cb;
+    const float* intensity; /* ignored for RT_AMBIENT */
+} rt_lights;
+
+typedef struct rt_ctx rt_ctx;
+
+/* library/ABI version string, static storage */
+const char* rt_version(void);
+
+/* Replaces nothing in the reference (it owns no device state): creates the per-device context (stream, events, scene buffers). */
+int32_t rt_ctx_create(rt_ctx** out, int32_t device_id);
+int32_t rt_ctx_destroy(rt_ctx* ctx);
+
+/* Text of the last error on this ctx (or of the last failed rt_ctx_create when ctx == NULL); never freed by the caller. */
+const char* rt_last_error(const rt_ctx* ctx);
+
+/* Camera::transform (display.rs:30-41): row-major 4x4; host-only helper, touches no device. */
+int32_t rt_camera_transform(float fov, float z_near, float z_far, float aspect_ratio, float m[16]);
+/* Camera::default() (display.rs:118-123): fov = 60f32.to_radians(), z_near = 0.01, z_far = 1000 */
+int32_t rt_camera_default(float* fov, float* z_near, float* z_far);
+
+/*
+ * Replaces the borrow of self.elements / self.lights at renderer.rs:37-38: copies the flattened scene to the device and
+ * precomputes the per-sphere constants the kernels use.  May be called again to replace the scene.
+ */
+int32_t rt_scene_upload(rt_ctx* ctx, const rt_objects* objects, const rt_lights* lights);
+
+/*
+ * Replaces the pixel loop of Renderer::render (renderer.rs:40-77 inside Framebuffer::update, display.rs:74-105) for the
+ * whole frame: writes h rows of w pixels, row 0 = top, into caller-owned HOST memory (w*h*4 bytes, or w*h*3 with
+ * RT_OUT_RGB8).  Blocking.  `m` is the row-major Mat4 of Camera::transform.  depth == 0 => RT_ERR_INVALID (the reference
+ * underflows `depth - 1` at renderer.rs:36).
+ */
+int32_t rt_render(rt_ctx* ctx, const float m[16], uint32_t w, uint32_t h, uint32_t depth, uint32_t flags, uint8_t* out_host);
+
+/*
+ * Same for the row band [y0, y1) of a w x h frame (the rayon row split of display.rs:90-93 turned into a per-GPU band):
+ * `out_host` receives (y1-y0) rows.  hit_idx_host (nullable, (y1-y0)*w int32) receives the index of the element the
+ * PRIMARY ray hit, or -1 — the data behind the grazing-edge report.
+ */
+int32_t rt_render_rows(rt_ctx* ctx, const float m[16], uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t depth, uint32_t flags,
+                       uint8_t* out_host, int32_t* hit_idx_host);
+
+/*
+ * Device-resident variant: `d_out` (and nullable `d_hit_idx`) are DEVICE pointers on ctx's device; the kernels are enqueued on
+ * `stream` (a hipStream_t; NULL => ctx's own stream) and the call returns without synchronising.  This is what a multi-GPU
+ * host uses per rank before gathering the bands (RCCL) — and what bench.py times.
+ */
+int32_t rt_render_rows_device(rt_ctx* ctx, const float m[16], uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t depth, uint32_t flags,
+                              void* d_out, void* d_hit_idx, void* stream);
+
+/* Elapsed GPU time (ms, hipEvent) of the kernels of the most recent rt_render* on this ctx; synchronises on its end event. */
+int32_t rt_last_kernel_ms(rt_ctx* ctx, float* ms);
+
+/*
+ * Host-only introspection of the scene preprocessing done by rt_scene_upload (no device needed; used by the CPU tests):
+ * for n spheres writes filt[4*n] = (cx', cy', cz', 0) of the conservative primary-ray filter  d.c' - 1 >= 0  and
+ * cls[n] = 1 if the sphere is filterable, 0 if it is always tested exactly.  See DESIGN.md "primary-ray filter".
+ */
+int32_t rt_debug_prepare_spheres(const rt_objects* objects, float* filt, uint8_t* cls);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,56 @@
+"""Row-band split of one frame across ranks and the gather of the bands to rank 0.
+
+The reference parallelises over image rows with rayon (display.rs:90-93); across GPUs the same axis is cut into
+contiguous bands: rank r renders rows [r*H/G, (r+1)*H/G) with GLOBAL row indices in the ray formula (display.rs:99),
+no exchange during rendering, one gather (RCCL over xGMI through torch.distributed's "nccl" backend; "gloo" on CPU in
+the tests) of the finished bands to rank 0.  torch is plumbing here: device memory, streams, the process group.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+
+def band_rows(h: int, world: int, rank: int) -> Tuple[int, int]:
+    """Rows [y0, y1) of rank `rank` when an h-row frame is cut into `world` contiguous bands."""
+    if world < 1 or not (0 <= rank < world):
+        raise ValueError("bad world/rank")
+    return (rank * h) // world, ((rank + 1) * h) // world
+
+
+def max_band_rows(h: int, world: int) -> int:
+    return max(band_rows(h, world, r)[1] - band_rows(h, world, r)[0] for r in range(world))
+
+
+def gather_bands(local_band, h: int, world: int, rank: int, group=None, gather_list=None):
+    """Gather per-rank bands (torch uint8 tensors [rows_r, w, ch], padded to the largest band) to rank 0.
+
+    Returns the assembled [h, w, ch] frame on rank 0, None elsewhere.  `local_band` must already have
+    max_band_rows(h, world) rows (only the first rows_r are meaningful) so every rank contributes an equal-size buffer
+    to the collective.  With world == 1 no collective is issued.
+    """
+    import torch
+    import torch.distributed as dist
+
+    rows_max = max_band_rows(h, world)
+    if local_band.shape[0] != rows_max:
+        raise ValueError(f"band buffer must have {rows_max} rows, got {local_band.shape[0]}")
+    if world == 1:
+        return local_band[:h]
+    if rank == 0:
+        if gather_list is None:
+            gather_list = [torch.empty_like(local_band) for _ in range(world)]
+        dist.gather(local_band, gather_list=gather_list, dst=0, group=group)
+        parts = []
+        for r in range(world):
+            y0, y1 = band_rows(h, world, r)
+            parts.append(gather_list[r][: y1 - y0])
+        return torch.cat(parts, dim=0)
+    dist.gather(local_band, gather_list=None, dst=0, group=group)
+    return None
+
+
+def render_frame_distributed(render_band: Callable[[int, int], "object"], h: int, world: int, rank: int, group=None):
+    """render_band(y0, y1) -> padded band tensor; returns the full frame on rank 0."""
+    y0, y1 = band_rows(h, world, rank)
+    band = render_band(y0, y1)
+    return gather_bands(band, h, world, rank, group)

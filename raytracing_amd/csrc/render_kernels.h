@@ -1,0 +1,36 @@
+// render_kernels.h — launch interface of the gfx950 render kernels (device code in render_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace rtamd {
+
+struct RenderArgs {
+    float m[12];  // rows 0..2 of the row-major camera Mat4 (row 3 only feeds w, which vec3.rs:702-707 drops)
+    uint32_t w, h;    // full frame size (ray formula uses global pixel indices, display.rs:99)
+    uint32_t y0, y1;  // row band rendered by this launch
+    uint32_t depth;   // renderer.rs:32
+    uint32_t flags;   // RT_SHADOWS | RT_OUT_RGB8
+    int32_t n, n_pad, n_always, n_lights;
+    const float4* filt;     // n_pad
+    const float4* sph;      // n_pad (cx,cy,cz,k)
+    const float4* sph_r;    // n_pad (cx,cy,cz,radius)
+    const float4* refl;     // n_pad
+    const int32_t* always;  // n_always
+    const float4* lpos;     // n_lights
+    const float4* lcol;     // n_lights
+    uint8_t* out;           // band rows, 4 or 3 B/pixel
+    int32_t* hit_idx;       // nullable
+};
+
+// Enqueue the render of args.[y0,y1) on `stream`. Returns the HIP status of the launch.
+hipError_t launch_render(const RenderArgs& args, hipStream_t stream);
+
+// Name of the kernel variant launch_render picks for these args (for profiles / bench output).
+const char* render_kernel_name(const RenderArgs& args);
+
+// Flops executed per primary-ray/sphere filter test by the hot loop (for roofline accounting).
+constexpr int kFilterFlopsPerTest = 6;  // three v_fma_f32
+
+}  // namespace rtamd

@@ -1,0 +1,263 @@
+// rt_capi.hip — the extern "C" boundary declared in include/rt_mi355x.h (host code; kernels live in render_kernels.hip).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "render_kernels.h"
+#include "rt_mi355x.h"
+#include "scene_prep.h"
+
+using namespace rtamd;
+
+struct rt_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    std::string err;
+    // device copies of the prepared scene
+    bool have_scene = false;
+    int32_t n = 0, n_pad = 0, n_always = 0, n_lights = 0;
+    void* d_scene = nullptr;  // one allocation, sub-arrays below point into it
+    size_t scene_bytes = 0;
+    const float4 *d_filt = nullptr, *d_sph = nullptr, *d_sph_r = nullptr, *d_refl = nullptr, *d_lpos = nullptr, *d_lcol = nullptr;
+    const int32_t* d_always = nullptr;
+    // staging for the host-output entry points
+    void* d_out = nullptr;
+    size_t d_out_bytes = 0;
+    void* d_hit = nullptr;
+    size_t d_hit_bytes = 0;
+};
+
+static thread_local std::string g_create_err;
+
+static int32_t fail(rt_ctx* ctx, int32_t code, const std::string& msg)
+{
+    if (ctx)
+        ctx->err = msg;
+    else
+        g_create_err = msg;
+    return code;
+}
+
+static int32_t fail_hip(rt_ctx* ctx, hipError_t e, const char* what)
+{
+    return fail(ctx, RT_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define RT_HIP(ctx, call)                                      \
+    do {                                                       \
+        hipError_t e_ = (call);                                \
+        if (e_ != hipSuccess) return fail_hip(ctx, e_, #call); \
+    } while (0)
+
+extern "C" {
+
+const char* rt_version(void) { return "rt_mi355x 0.1 (gfx950)"; }
+
+const char* rt_last_error(const rt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int32_t rt_camera_transform(float fov, float z_near, float z_far, float aspect_ratio, float m[16])
+{
+    if (!m) return RT_ERR_INVALID;
+    camera_transform(fov, z_near, z_far, aspect_ratio, m);
+    return RT_OK;
+}
+
+int32_t rt_camera_default(float* fov, float* z_near, float* z_far)
+{
+    if (!fov || !z_near || !z_far) return RT_ERR_INVALID;
+    const float pi = 3.14159265358979323846f;
+    const float rads_per_deg = pi / 180.0f;  // f32::to_radians (display.rs:121)
+    *fov = 60.0f * rads_per_deg;
+    *z_near = 0.01f;
+    *z_far = 1000.0f;
+    return RT_OK;
+}
+
+int32_t rt_debug_prepare_spheres(const rt_objects* o, float* filt, uint8_t* cls)
+{
+    if (!o || !filt || !cls || o->n < 0) return RT_ERR_INVALID;
+    if (o->n > 0 && (!o->cx || !o->cy || !o->cz || !o->radius)) return RT_ERR_INVALID;
+    prepare_filter(o->n, o->cx, o->cy, o->cz, o->radius, reinterpret_cast<f4*>(filt), cls, nullptr);
+    return RT_OK;
+}
+
+int32_t rt_ctx_create(rt_ctx** out, int32_t device_id)
+{
+    if (!out) return fail(nullptr, RT_ERR_INVALID, "rt_ctx_create: out is null");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) return fail(nullptr, RT_ERR_NO_DEVICE, std::string("no HIP device: ") + hipGetErrorString(e));
+    if (device_id < 0 || device_id >= count) return fail(nullptr, RT_ERR_NO_DEVICE, "device id out of range");
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device_id);
+    if (e != hipSuccess) return fail_hip(nullptr, e, "hipGetDeviceProperties");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, RT_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only");
+    rt_ctx* c = new (std::nothrow) rt_ctx();
+    if (!c) return fail(nullptr, RT_ERR_HIP, "out of host memory");
+    c->device = device_id;
+    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
+        int32_t rc = fail_hip(nullptr, e, "context setup");
+        rt_ctx_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return RT_OK;
+}
+
+int32_t rt_ctx_destroy(rt_ctx* c)
+{
+    if (!c) return RT_OK;
+    if (c->device >= 0) (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->d_scene) (void)hipFree(c->d_scene);
+    if (c->d_out) (void)hipFree(c->d_out);
+    if (c->d_hit) (void)hipFree(c->d_hit);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return RT_OK;
+}
+
+int32_t rt_scene_upload(rt_ctx* c, const rt_objects* o, const rt_lights* l)
+{
+    if (!c) return RT_ERR_INVALID;
+    PreparedScene ps;
+    std::string msg = prepare_scene(o, l, ps);
+    if (!msg.empty()) return fail(c, RT_ERR_INVALID, "rt_scene_upload: " + msg);
+    RT_HIP(c, hipSetDevice(c->device));
+
+    // one packed allocation: filt | sph | sph_r | refl | lpos | lcol | always   (all 16-byte aligned)
+    const size_t np = (size_t)ps.n_pad, nl = (size_t)ps.n_lights, na = ps.always.size();
+    const size_t off_filt = 0, off_sph = off_filt + np * 16, off_sph_r = off_sph + np * 16, off_refl = off_sph_r + np * 16;
+    const size_t off_lpos = off_refl + np * 16, off_lcol = off_lpos + (nl ? nl : 1) * 16, off_alw = off_lcol + (nl ? nl : 1) * 16;
+    const size_t total = off_alw + ((na ? na : 1) * 4 + 15) / 16 * 16;
+    std::vector<unsigned char> host(total, 0);
+    std::memcpy(host.data() + off_filt, ps.filt.data(), np * 16);
+    std::memcpy(host.data() + off_sph, ps.sph.data(), np * 16);
+    std::memcpy(host.data() + off_sph_r, ps.sph_r.data(), np * 16);
+    std::memcpy(host.data() + off_refl, ps.refl.data(), np * 16);
+    if (nl) std::memcpy(host.data() + off_lpos, ps.lpos.data(), nl * 16);
+    if (nl) std::memcpy(host.data() + off_lcol, ps.lcol.data(), nl * 16);
+    if (na) std::memcpy(host.data() + off_alw, ps.always.data(), na * 4);
+
+    RT_HIP(c, hipStreamSynchronize(c->stream));  // no render may still read the old scene
+    if (total > c->scene_bytes) {
+        if (c->d_scene) RT_HIP(c, hipFree(c->d_scene));
+        c->d_scene = nullptr;
+        c->scene_bytes = 0;
+        c->have_scene = false;
+        RT_HIP(c, hipMalloc(&c->d_scene, total));
+        c->scene_bytes = total;
+    }
+    RT_HIP(c, hipMemcpyAsync(c->d_scene, host.data(), total, hipMemcpyHostToDevice, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    const char* base = static_cast<const char*>(c->d_scene);
+    c->d_filt = reinterpret_cast<const float4*>(base + off_filt);
+    c->d_sph = reinterpret_cast<const float4*>(base + off_sph);
+    c->d_sph_r = reinterpret_cast<const float4*>(base + off_sph_r);
+    c->d_refl = reinterpret_cast<const float4*>(base + off_refl);
+    c->d_lpos = reinterpret_cast<const float4*>(base + off_lpos);
+    c->d_lcol = reinterpret_cast<const float4*>(base + off_lcol);
+    c->d_always = reinterpret_cast<const int32_t*>(base + off_alw);
+    c->n = ps.n;
+    c->n_pad = ps.n_pad;
+    c->n_always = (int32_t)na;
+    c->n_lights = ps.n_lights;
+    c->have_scene = true;
+    return RT_OK;
+}
+
+static int32_t check_render_args(rt_ctx* c, const float* m, uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t depth, uint32_t flags)
+{
+    if (!c) return RT_ERR_INVALID;
+    if (!m) return fail(c, RT_ERR_INVALID, "camera matrix is null");
+    if (!c->have_scene) return fail(c, RT_ERR_NO_SCENE, "rt_scene_upload has not been called");
+    if (depth == 0) return fail(c, RT_ERR_INVALID, "depth must be >= 1 (the reference computes depth - 1 on usize, renderer.rs:36)");
+    if (w == 0 || h == 0) return fail(c, RT_ERR_INVALID, "empty frame");
+    if (y0 > y1 || y1 > h) return fail(c, RT_ERR_INVALID, "row band outside the frame");
+    if (flags & ~(RT_SHADOWS | RT_OUT_RGB8)) return fail(c, RT_ERR_INVALID, "unknown flag bits");
+    if ((uint64_t)w * (uint64_t)h > (1ull << 31)) return fail(c, RT_ERR_TOO_LARGE, "frame larger than 2^31 pixels");
+    return RT_OK;
+}
+
+int32_t rt_render_rows_device(rt_ctx* c, const float m[16], uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t depth, uint32_t flags,
+                              void* d_out, void* d_hit_idx, void* stream)
+{
+    int32_t rc = check_render_args(c, m, w, h, y0, y1, depth, flags);
+    if (rc != RT_OK) return rc;
+    if (y1 > y0 && !d_out) return fail(c, RT_ERR_INVALID, "output pointer is null");
+    RT_HIP(c, hipSetDevice(c->device));
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    RenderArgs a;
+    std::memcpy(a.m, m, sizeof(a.m));
+    a.w = w; a.h = h; a.y0 = y0; a.y1 = y1; a.depth = depth; a.flags = flags;
+    a.n = c->n; a.n_pad = c->n_pad; a.n_always = c->n_always; a.n_lights = c->n_lights;
+    a.filt = c->d_filt; a.sph = c->d_sph; a.sph_r = c->d_sph_r; a.refl = c->d_refl; a.always = c->d_always; a.lpos = c->d_lpos; a.lcol = c->d_lcol;
+    a.out = static_cast<uint8_t*>(d_out);
+    a.hit_idx = static_cast<int32_t*>(d_hit_idx);
+    RT_HIP(c, hipEventRecord(c->ev0, st));
+    RT_HIP(c, launch_render(a, st));
+    RT_HIP(c, hipEventRecord(c->ev1, st));
+    c->timed = true;
+    return RT_OK;
+}
+
+int32_t rt_render_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t depth, uint32_t flags,
+                       uint8_t* out_host, int32_t* hit_idx_host)
+{
+    int32_t rc = check_render_args(c, m, w, h, y0, y1, depth, flags);
+    if (rc != RT_OK) return rc;
+    if (y1 == y0) return RT_OK;
+    if (!out_host) return fail(c, RT_ERR_INVALID, "output pointer is null");
+    RT_HIP(c, hipSetDevice(c->device));
+    const size_t npix = (size_t)(y1 - y0) * w;
+    const size_t bytes = npix * ((flags & RT_OUT_RGB8) ? 3 : 4);
+    if (bytes > c->d_out_bytes) {
+        if (c->d_out) RT_HIP(c, hipFree(c->d_out));
+        c->d_out = nullptr;
+        c->d_out_bytes = 0;
+        RT_HIP(c, hipMalloc(&c->d_out, bytes));
+        c->d_out_bytes = bytes;
+    }
+    if (hit_idx_host && npix * 4 > c->d_hit_bytes) {
+        if (c->d_hit) RT_HIP(c, hipFree(c->d_hit));
+        c->d_hit = nullptr;
+        c->d_hit_bytes = 0;
+        RT_HIP(c, hipMalloc(&c->d_hit, npix * 4));
+        c->d_hit_bytes = npix * 4;
+    }
+    rc = rt_render_rows_device(c, m, w, h, y0, y1, depth, flags, c->d_out, hit_idx_host ? c->d_hit : nullptr, nullptr);
+    if (rc != RT_OK) return rc;
+    RT_HIP(c, hipMemcpyAsync(out_host, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));
+    if (hit_idx_host) RT_HIP(c, hipMemcpyAsync(hit_idx_host, c->d_hit, npix * 4, hipMemcpyDeviceToHost, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+int32_t rt_render(rt_ctx* c, const float m[16], uint32_t w, uint32_t h, uint32_t depth, uint32_t flags, uint8_t* out_host)
+{
+    return rt_render_rows(c, m, w, h, 0, h, depth, flags, out_host, nullptr);
+}
+
+int32_t rt_last_kernel_ms(rt_ctx* c, float* ms)
+{
+    if (!c || !ms) return RT_ERR_INVALID;
+    if (!c->timed) return fail(c, RT_ERR_INVALID, "no render has been enqueued on this context");
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipEventSynchronize(c->ev1));
+    RT_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,41 @@
+// scene_prep.h — host-side flattening/preprocessing of the scene for the gfx950 kernels (no device code).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "rt_mi355x.h"
+
+namespace rtamd {
+
+struct f4 {
+    float x, y, z, w;
+};
+
+// Spheres are padded to a multiple of this many entries so the filter loop never needs a bounds check.
+constexpr int kSphereBlockPad = 16;
+
+struct PreparedScene {
+    int32_t n = 0;       // elements (renderer.rs:37)
+    int32_t n_pad = 0;   // n rounded up to kSphereBlockPad
+    int32_t n_lights = 0;
+    std::vector<f4> filt;        // n_pad: (cx', cy', cz', 0) — conservative primary-ray filter d.c' - 1 >= 0 ; (0,0,0,0) = never passes
+    std::vector<f4> sph;         // n_pad: (cx, cy, cz, k) with k = dot3(c,c) - r*r in the reference's order (sphere.rs:29 with origin 0)
+    std::vector<f4> sph_r;       // n_pad: (cx, cy, cz, radius) for general-origin rays (bounces, shadow rays)
+    std::vector<f4> refl;        // n_pad: Material.reflectiveness (element.rs:18), w unused
+    std::vector<int32_t> always; // indices of spheres the filter cannot cover (origin inside / on / absurd values): tested exactly for every pixel
+    std::vector<uint8_t> cls;    // n: 1 = filterable, 0 = always
+    std::vector<f4> lpos;        // n_lights: (px, py, pz, intensity)
+    std::vector<f4> lcol;        // n_lights: (cr, cg, cb, kind as float: 0 = point, 1 = ambient)
+};
+
+// Returns empty string on success, else an error text. Validates kinds and pointers.
+std::string prepare_scene(const rt_objects* o, const rt_lights* l, PreparedScene& out);
+
+// Filter constants only (used by rt_debug_prepare_spheres and prepare_scene).
+void prepare_filter(int32_t n, const float* cx, const float* cy, const float* cz, const float* radius, f4* filt, uint8_t* cls, float* k_out);
+
+// Camera::transform (display.rs:30-41)
+void camera_transform(float fov, float z_near, float z_far, float aspect, float m[16]);
+
+}  // namespace rtamd
