@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: primary rays/s on config C3 (3840x2160, 1024 spheres, 4 point lights, depth 1).
+
+A step = one pass of the hot path over one frame: every rank renders its row band of the SAME frame with the HIP kernel
+(C ABI rt_render_rows_device, scene already resident in HBM) and the bands are gathered to rank 0 (RCCL through
+torch.distributed "nccl"); with --gpus 1 no collective is issued.  Total work per step is fixed (one frame) => strong scaling.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3|C4|C5] [--no-cpu-baseline]
+  N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (metric/value/roofline/cpu_baseline ...).  The oracle is used only for the cpu_baseline leg.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+FLOPS_PER_TEST = 6             # the hot loop executes three v_fma_f32 per (pixel, sphere) pair (render_kernels.h)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="C3", choices=["C3", "C4", "C5"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from raytracing_amd import bands, capi, scenegen
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    w, h, objs, lights = scenegen.config(args.config)
+    m = capi.camera_transform(*capi.camera_default(), np.float32(w) / np.float32(h))
+    ctx = capi.Context(local_rank)
+    ctx.scene_upload(objs, lights)
+
+    y0, y1 = bands.band_rows(h, world, rank)
+    rows_max = bands.max_band_rows(h, world)
+    band = torch.zeros((rows_max, w, 4), dtype=torch.uint8, device=dev)
+    gather_list = [torch.empty_like(band) for _ in range(world)] if (world > 1 and rank == 0) else None
+    # a non-default stream: its handle is what the C ABI launches on, and the torch events below are recorded on it
+    stream = torch.cuda.Stream(dev)
+    torch.cuda.set_stream(stream)
+
+    def step(ev=None):
+        if ev is not None:
+            ev[0].record(stream)
+        ctx.render_rows_device(m, w, h, y0, y1, 1, 0, band.data_ptr(), 0, stream.cuda_stream)
+        if ev is not None:
+            ev[1].record(stream)
+        if world > 1:
+            if rank == 0:
+                dist.gather(band, gather_list=gather_list, dst=0)
+            else:
+                dist.gather(band, gather_list=None, dst=0)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    fence()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    fence()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)  # HIP events on the launch stream
+
+    tmax = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed_max, kern_ms_max = float(tmax[0]), float(tmax[1])
+
+    if rank == 0:
+        rays_per_step = w * h
+        value = rays_per_step * args.steps / elapsed_max
+        # roofline of the dominant kernel (this rank's launch): executed flops of the filter loop / its own duration
+        my_tests = (y1 - y0) * w * objs.n
+        achieved = my_tests * FLOPS_PER_TEST / (kern_ms * 1e-3) / 1e12
+        out = {
+            "metric": "primary rays/sec at 4K, 1024 spheres (config %s)" % args.config,
+            "value": value,
+            "unit": "rays/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (SCENE-GEN v1, PCG32 seed 42)",
+            "config": {"workload": "%s: %dx%d frame, %d spheres, %d point lights, depth 1, RGBA8 out" % (args.config, w, h, objs.n, lights.n),
+                       "parallelism": "row bands x%d, gather to rank 0" % world, "kernel": "render_kernel<primary>"},
+            "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
+                         "kernel_ms": kern_ms, "kernel_ms_max_over_ranks": kern_ms_max,
+                         "flops_counted": "%d per (pixel,sphere) filter test x %d tests per launch" % (FLOPS_PER_TEST, my_tests)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(objs, lights, m, w, h)
+        print(json.dumps(out), flush=True)
+
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(objs, lights, m, w, h):
+    """The CPU oracle (C restatement of the reference, row-parallel like rayon) timed on this host on a bounded sample."""
+    from tests import oracle_py
+    orc = oracle_py.load()
+    threads = min(orc.default_threads(), 16)
+    row_step = 4
+    t0 = time.perf_counter()
+    orc.render(objs, lights, m, w, h, row_step=row_step, nthreads=threads)
+    dt = time.perf_counter() - t0
+    rows = (h + row_step - 1) // row_step
+    return {"value": rows * w / dt, "unit": "rays/s", "cores": threads, "kind": "port",
+            "sample": "every %dth row of the same frame (%d rows x %d px), %d threads, %.2f s wall" % (row_step, rows, w, threads, dt)}
+
+
+if __name__ == "__main__":
+    main()

@@ -167,11 +167,12 @@ __device__ __forceinline__ void closest_general(const RenderArgs& A, bool active
     }
 }
 
-template <int PX, int PY, int B, bool USE_LDS, bool GENERAL>
+template <int PX, int PY, int B, bool GENERAL>
 __global__ __launch_bounds__(kWaves * 64) void render_kernel(const RenderArgs A)
 {
     constexpr int P = PX * PY;
-    __shared__ float4 s_filt[USE_LDS ? kChunk : 1];
+    // filter constants of the current chunk, SoA so that four spheres' x (y, z) come back in one broadcast ds_read_b128
+    __shared__ __attribute__((aligned(16))) float s_x[kChunk], s_y[kChunk], s_z[kChunk];
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
@@ -224,26 +225,39 @@ __global__ __launch_bounds__(kWaves * 64) void render_kernel(const RenderArgs A)
     // ---- hot loop: conservative 3-FMA filter over the whole list, exact test only for candidate blocks ----
     for (int c0 = 0; c0 < A.n_pad; c0 += kChunk) {
         const int cn = min(kChunk, A.n_pad - c0);
-        if (USE_LDS) {
-            __syncthreads();
-            for (int i = tid; i < cn; i += kWaves * 64) s_filt[i] = A.filt[c0 + i];
-            __syncthreads();
+        __syncthreads();  // every wave is done reading the previous chunk
+        for (int i = tid; i < cn; i += kWaves * 64) {
+            const float4 q = A.filt[c0 + i];
+            s_x[i] = q.x;
+            s_y[i] = q.y;
+            s_z[i] = q.z;
         }
+        __syncthreads();
         for (int s0 = 0; s0 < cn; s0 += B) {
             float m = -1.0f;
+            float qx[B], qy[B], qz[B];
+#pragma unroll
+            for (int g = 0; g < B; g += 4) {  // wave-uniform address: broadcast ds_read_b128, four spheres per read
+                const float4 vx = *reinterpret_cast<const float4*>(&s_x[s0 + g]);
+                const float4 vy = *reinterpret_cast<const float4*>(&s_y[s0 + g]);
+                const float4 vz = *reinterpret_cast<const float4*>(&s_z[s0 + g]);
+                qx[g] = vx.x; qx[g + 1] = vx.y; qx[g + 2] = vx.z; qx[g + 3] = vx.w;
+                qy[g] = vy.x; qy[g + 1] = vy.y; qy[g + 2] = vy.z; qy[g + 3] = vy.w;
+                qz[g] = vz.x; qz[g + 1] = vz.y; qz[g + 2] = vz.z; qz[g + 3] = vz.w;
+            }
 #pragma unroll
             for (int b = 0; b < B; ++b) {
-                const float4 q = USE_LDS ? s_filt[s0 + b] : A.filt[c0 + s0 + b];
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
-                    float f = __builtin_fmaf(dx[p], q.x, __builtin_fmaf(dy[p], q.y, __builtin_fmaf(dz[p], q.z, -1.0f)));
+                    // 3 x v_fma_f32 per (pixel, sphere); the block maximum folds two results per v_max3_f32
+                    float f = __builtin_fmaf(dx[p], qx[b], __builtin_fmaf(dy[p], qy[b], __builtin_fmaf(dz[p], qz[b], -1.0f)));
                     m = __builtin_fmaxf(m, f);
                 }
             }
             if (__builtin_amdgcn_ballot_w64(m >= 0.0f) != 0ull) {
                 // rare: some lane has a candidate in this block. Find the spheres, run the reference's exact test.
                 for (int b = 0; b < B; ++b) {
-                    const float4 q = USE_LDS ? s_filt[s0 + b] : A.filt[c0 + s0 + b];
+                    const float4 q = A.filt[c0 + s0 + b];
                     bool cand = false;
 #pragma unroll
                     for (int p = 0; p < P; ++p) {
@@ -324,12 +338,12 @@ __global__ __launch_bounds__(kWaves * 64) void render_kernel(const RenderArgs A)
     }
 }
 
-template <int PX, int PY, int B, bool USE_LDS, bool GENERAL>
+template <int PX, int PY, int B, bool GENERAL>
 hipError_t launch_variant(const RenderArgs& args, hipStream_t stream)
 {
     const uint32_t rows = args.y1 - args.y0;
     dim3 grid((args.w + kWaves * kLX * PX - 1) / (kWaves * kLX * PX), (rows + kLY * PY - 1) / (kLY * PY));
-    hipLaunchKernelGGL((render_kernel<PX, PY, B, USE_LDS, GENERAL>), grid, dim3(kWaves * 64), 0, stream, args);
+    hipLaunchKernelGGL((render_kernel<PX, PY, B, GENERAL>), grid, dim3(kWaves * 64), 0, stream, args);
     return hipGetLastError();
 }
 
@@ -337,13 +351,15 @@ inline bool is_general(const RenderArgs& a) { return a.depth > 1u || (a.flags & 
 
 }  // namespace
 
+// Geometry chosen by the sweep recorded in profiles/r01_tuning.md: 16x4 lanes, 1x4 pixels per lane (16x16-pixel wave tile),
+// one vote per 8 spheres.
 hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
 {
     if (args.y1 <= args.y0 || args.w == 0) return hipSuccess;
-    if (is_general(args)) return launch_variant<1, 4, 8, true, true>(args, stream);
-    return launch_variant<1, 4, 8, true, false>(args, stream);
+    if (is_general(args)) return launch_variant<1, 4, 8, true>(args, stream);
+    return launch_variant<1, 4, 8, false>(args, stream);
 }
 
-const char* render_kernel_name(const RenderArgs& args) { return is_general(args) ? "render_kernel<1,4,8,lds,general>" : "render_kernel<1,4,8,lds,primary>"; }
+const char* render_kernel_name(const RenderArgs& args) { return is_general(args) ? "render_kernel<1,4,8,general>" : "render_kernel<1,4,8,primary>"; }
 
 }  // namespace rtamd

@@ -1,0 +1,82 @@
+"""CPU, world_size 2 (gloo): the row-band split + gather of raytracing_amd.bands reassembles exactly the single-process
+frame.  The band renderer here is the ORACLE (tests may use it); on the GPU the same host code is fed by the HIP kernel."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from raytracing_amd import bands, scene, scenegen
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_band_rows_partition():
+    for h in (1, 7, 100, 2160, 4320):
+        for world in (1, 2, 3, 4, 8):
+            rows = [bands.band_rows(h, world, r) for r in range(world)]
+            assert rows[0][0] == 0 and rows[-1][1] == h
+            for (a0, a1), (b0, b1) in zip(rows[:-1], rows[1:]):
+                assert a1 == b0 and a0 <= a1
+            assert bands.max_band_rows(h, world) == max(b - a for a, b in rows)
+    assert bands.band_rows(2160, 8, 3) == (810, 1080)
+    with pytest.raises(ValueError):
+        bands.band_rows(10, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, w, h, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests import oracle_py
+    orc = oracle_py.load()
+    objs, lights = scenegen.generate(w, h, 40, 3, seed=5)
+    m = orc.default_camera(w, h)
+    rows_max = bands.max_band_rows(h, world)
+
+    def render_band(y0, y1):
+        band = torch.zeros((rows_max, w, 4), dtype=torch.uint8)
+        band[: y1 - y0] = torch.from_numpy(orc.render(objs, lights, m, w, h, y0=y0, y1=y1, nthreads=1))
+        return band
+
+    frame = bands.render_frame_distributed(render_band, h, world, rank)
+    if rank == 0:
+        np.save(os.path.join(outdir, "frame.npy"), frame.numpy())
+    else:
+        assert frame is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("h", [60, 61])
+def test_two_rank_gather_matches_single_process(tmp_path, oracle, h):
+    w, world = 80, 2
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, w, h, str(tmp_path)), nprocs=world, join=True)
+    got = np.load(tmp_path / "frame.npy")
+    objs, lights = scenegen.generate(w, h, 40, 3, seed=5)
+    ref = oracle.render(objs, lights, oracle.default_camera(w, h), w, h)
+    assert got.shape == ref.shape
+    assert np.array_equal(got, ref)
+
+
+def test_single_rank_needs_no_process_group(oracle):
+    w, h = 32, 20
+    elements, lights = scene.default_scene()
+    objs, lts = scene.flatten_elements(elements), scene.flatten_lights(lights)
+    m = oracle.default_camera(w, h)
+    frame = bands.render_frame_distributed(lambda y0, y1: torch.from_numpy(oracle.render(objs, lts, m, w, h, y0=y0, y1=y1)), h, 1, 0)
+    assert np.array_equal(frame.numpy(), oracle.render(objs, lts, m, w, h))
