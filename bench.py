@@ -143,7 +143,7 @@ def cpu_baseline(objs, lights, m, w, h):
     from tests import oracle_py
     orc = oracle_py.load()
     threads = min(orc.default_threads(), 16)
-    row_step = 4
+    row_step = 2
     t0 = time.perf_counter()
     orc.render(objs, lights, m, w, h, row_step=row_step, nthreads=threads)
     dt = time.perf_counter() - t0

@@ -1,0 +1,59 @@
+//! FFI binding of include/rt_mi355x.h (librt_mi355x.so). UNCOMPILED in this environment — see rust/README.md.
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_void};
+
+pub const RT_OK: i32 = 0;
+pub const RT_SPHERE: u8 = 0;
+pub const RT_POINT: u8 = 0;
+pub const RT_AMBIENT: u8 = 1;
+pub const RT_SHADOWS: u32 = 1;
+pub const RT_OUT_RGB8: u32 = 2;
+
+#[repr(C)]
+pub struct rt_objects {
+    pub n: i32,
+    pub kind: *const u8,
+    pub cx: *const f32,
+    pub cy: *const f32,
+    pub cz: *const f32,
+    pub radius: *const f32,
+    pub refl_r: *const f32,
+    pub refl_g: *const f32,
+    pub refl_b: *const f32,
+}
+
+#[repr(C)]
+pub struct rt_lights {
+    pub n: i32,
+    pub kind: *const u8,
+    pub px: *const f32,
+    pub py: *const f32,
+    pub pz: *const f32,
+    pub cr: *const f32,
+    pub cg: *const f32,
+    pub cb: *const f32,
+    pub intensity: *const f32,
+}
+
+#[repr(C)]
+pub struct rt_ctx {
+    _private: [u8; 0],
+}
+
+#[link(name = "rt_mi355x")]
+extern "C" {
+    pub fn rt_version() -> *const c_char;
+    pub fn rt_ctx_create(out: *mut *mut rt_ctx, device_id: i32) -> i32;
+    pub fn rt_ctx_destroy(ctx: *mut rt_ctx) -> i32;
+    pub fn rt_last_error(ctx: *const rt_ctx) -> *const c_char;
+    pub fn rt_camera_transform(fov: f32, z_near: f32, z_far: f32, aspect_ratio: f32, m: *mut f32) -> i32;
+    pub fn rt_camera_default(fov: *mut f32, z_near: *mut f32, z_far: *mut f32) -> i32;
+    pub fn rt_scene_upload(ctx: *mut rt_ctx, objects: *const rt_objects, lights: *const rt_lights) -> i32;
+    pub fn rt_render(ctx: *mut rt_ctx, m: *const f32, w: u32, h: u32, depth: u32, flags: u32, out_host: *mut u8) -> i32;
+    pub fn rt_render_rows(ctx: *mut rt_ctx, m: *const f32, w: u32, h: u32, y0: u32, y1: u32, depth: u32, flags: u32,
+                          out_host: *mut u8, hit_idx_host: *mut i32) -> i32;
+    pub fn rt_render_rows_device(ctx: *mut rt_ctx, m: *const f32, w: u32, h: u32, y0: u32, y1: u32, depth: u32, flags: u32,
+                                 d_out: *mut c_void, d_hit_idx: *mut c_void, stream: *mut c_void) -> i32;
+    pub fn rt_last_kernel_ms(ctx: *mut rt_ctx, ms: *mut f32) -> i32;
+    pub fn rt_debug_prepare_spheres(objects: *const rt_objects, filt: *mut f32, cls: *mut u8) -> i32;
+}

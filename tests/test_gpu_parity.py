@@ -193,3 +193,18 @@ def test_argument_errors(gpu_ctx, oracle):
         fresh.render(m, 8, 8, 1)
     assert e.value.code == capi.RT_ERR_NO_SCENE
     fresh.close()
+
+
+def test_cpp_host_mirror_main(tmp_path):
+    """examples/main (main.rs written against the C++ mirror of the reference's API) writes the reference's result.png."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(GOLDEN), "..", "examples", "main")
+    assert os.path.exists(exe), "build it first: make -C examples (done by __graft_entry__.build())"
+    r = subprocess.run([os.path.abspath(exe)], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "1298 lit pixels" in r.stdout
+    from PIL import Image
+    got = np.array(Image.open(tmp_path / "result.png"))
+    _assert_same(got, np.load(os.path.join(GOLDEN, "result_100x100.npy")), "C++ main result.png")
+    bad = subprocess.run([os.path.abspath(exe), "10", "10", "0"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 1 and "depth - 1" in bad.stderr
