@@ -3,7 +3,8 @@
 
 A step = one pass of the hot path over one frame: every rank renders its row band of the SAME frame with the HIP kernel
 (C ABI rt_render_rows_device, scene already resident in HBM) and the bands are gathered to rank 0 (RCCL through
-torch.distributed "nccl"); with --gpus 1 no collective is issued.  Total work per step is fixed (one frame) => strong scaling.
+torch.distributed "nccl", double-buffered so the gather of frame k overlaps the render of frame k+1); with --gpus 1 no
+collective is issued.  Total work per step is fixed (one frame) => strong scaling.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3|C4|C5] [--no-cpu-baseline]
   N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -61,25 +62,29 @@ def main():
 
     y0, y1 = bands.band_rows(h, world, rank)
     rows_max = bands.max_band_rows(h, world)
-    band = torch.zeros((rows_max, w, 4), dtype=torch.uint8, device=dev)
-    gather_list = [torch.empty_like(band) for _ in range(world)] if (world > 1 and rank == 0) else None
     # a non-default stream: its handle is what the C ABI launches on, and the torch events below are recorded on it
     stream = torch.cuda.Stream(dev)
     torch.cuda.set_stream(stream)
+    # two band buffers: the gather of frame k (async RCCL collective) overlaps the render of frame k+1
+    slots = 2
+    band_bufs = [torch.zeros((rows_max, w, 4), dtype=torch.uint8, device=dev) for _ in range(slots)]
+    gather_lists = [[torch.empty_like(band_bufs[0]) for _ in range(world)] if (world > 1 and rank == 0) else None for _ in range(slots)]
+    pipe = bands.GatherPipeline(world, rank, slots=slots)
+    frame_no = [0]
 
     def step(ev=None):
+        k = frame_no[0]
+        frame_no[0] += 1
+        s = pipe.begin(k)  # stream-level wait until the gather that last read band_bufs[s] is done
         if ev is not None:
             ev[0].record(stream)
-        ctx.render_rows_device(m, w, h, y0, y1, 1, 0, band.data_ptr(), 0, stream.cuda_stream)
+        ctx.render_rows_device(m, w, h, y0, y1, 1, 0, band_bufs[s].data_ptr(), 0, stream.cuda_stream)
         if ev is not None:
             ev[1].record(stream)
-        if world > 1:
-            if rank == 0:
-                dist.gather(band, gather_list=gather_list, dst=0)
-            else:
-                dist.gather(band, gather_list=None, dst=0)
+        pipe.submit(k, band_bufs[s], gather_lists[s])
 
     def fence():
+        pipe.drain()
         torch.cuda.synchronize(dev)
         if world > 1:
             dist.barrier()
@@ -123,7 +128,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic (SCENE-GEN v1, PCG32 seed 42)",
             "config": {"workload": "%s: %dx%d frame, %d spheres, %d point lights, depth 1, RGBA8 out" % (args.config, w, h, objs.n, lights.n),
-                       "parallelism": "row bands x%d, gather to rank 0" % world, "kernel": "render_kernel<primary>"},
+                       "parallelism": "row bands x%d, RCCL gather to rank 0 overlapped with the next frame's render" % world, "kernel": "render_kernel<primary>"},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
                          "kernel_ms": kern_ms, "kernel_ms_max_over_ranks": kern_ms_max,

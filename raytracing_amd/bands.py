@@ -49,6 +49,57 @@ def gather_bands(local_band, h: int, world: int, rank: int, group=None, gather_l
     return None
 
 
+class GatherPipeline:
+    """Double-buffered render -> gather pipeline: the gather of frame k (async collective) overlaps the render of frame k+1.
+
+    Usage per frame k:   s = pipe.begin(k)          # makes the current stream wait until slot s's previous gather is done
+                         <render the band into band_buffers[s]>
+                         pipe.submit(k, band_buffers[s], gather_lists[s] on rank 0 else None)
+    and pipe.drain() at the end.  With world == 1 every call is a no-op (no collective exists).  Works with "nccl"
+    (RCCL; Work.wait() is a stream-level wait, the host never blocks) and with "gloo" (CPU tests; wait() blocks).
+    """
+
+    def __init__(self, world: int, rank: int, slots: int = 2, group=None):
+        if slots < 1:
+            raise ValueError("need at least one slot")
+        self.world, self.rank, self.slots, self.group = world, rank, slots, group
+        self._work = [None] * slots
+
+    def begin(self, k: int) -> int:
+        s = k % self.slots
+        if self._work[s] is not None:
+            self._work[s].wait()
+            self._work[s] = None
+        return s
+
+    def submit(self, k: int, band, gather_list=None):
+        if self.world == 1:
+            return
+        import torch.distributed as dist
+        s = k % self.slots
+        if self._work[s] is not None:
+            raise RuntimeError("slot reused without begin()")
+        if self.rank == 0 and gather_list is None:
+            raise ValueError("rank 0 needs a gather_list")
+        self._work[s] = dist.gather(band, gather_list=gather_list if self.rank == 0 else None, dst=0, group=self.group, async_op=True)
+
+    def drain(self):
+        for s in range(self.slots):
+            if self._work[s] is not None:
+                self._work[s].wait()
+                self._work[s] = None
+
+
+def assemble(gather_list, h: int, world: int):
+    """Rank 0: cut the padding off the gathered bands and stack them into the [h, w, ch] frame."""
+    import torch
+    parts = []
+    for r in range(world):
+        y0, y1 = band_rows(h, world, r)
+        parts.append(gather_list[r][: y1 - y0])
+    return torch.cat(parts, dim=0)
+
+
 def render_frame_distributed(render_band: Callable[[int, int], "object"], h: int, world: int, rank: int, group=None):
     """render_band(y0, y1) -> padded band tensor; returns the full frame on rank 0."""
     y0, y1 = band_rows(h, world, rank)
