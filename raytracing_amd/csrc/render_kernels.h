@@ -16,6 +16,7 @@ struct RenderArgs {
     const float4* filt;     // n_pad
     const float4* sph;      // n_pad (cx,cy,cz,k)
     const float4* sph_r;    // n_pad (cx,cy,cz,radius)
+    const float4* gen;      // n_pad (cx,cy,cz,-rho): general-origin filter constants
     const float4* refl;     // n_pad
     const int32_t* always;  // n_always
     const float4* lpos;     // n_lights

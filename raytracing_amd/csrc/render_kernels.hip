@@ -105,27 +105,9 @@ __device__ __forceinline__ void unit3(float& x, float& y, float& z)
     z = z / n;
 }
 
-// EXTENSION RT_SHADOWS: is the segment p -> lp blocked? `need` lanes take part; wave-level early-out once every
-// needing lane is occluded. Exact general-origin test, so the CPU oracle's any-hit answer is reproduced bit for bit.
-__device__ __forceinline__ bool occluded(const RenderArgs& A, bool need, float px, float py, float pz, float lx, float ly, float lz)
-{
-    float vx = lx - px, vy = ly - py, vz = lz - pz;
-    float dist = sqrtf(dot3_ref(vx, vy, vz, vx, vy, vz));
-    float dx = vx / dist, dy = vy / dist, dz = vz / dist;
-    bool occ = false;
-    for (int k = 0; k < A.n; ++k) {
-        if (__builtin_amdgcn_ballot_w64(need && !occ) == 0ull) break;
-        float t;
-        bool h = hit_general_exact(px, py, pz, dx, dy, dz, A.sph_r[k], t);
-        occ = occ || (need && h && t > RT_SHADOW_EPS && t < dist);
-    }
-    return occ;
-}
-
 // renderer.rs:59-66 — c = color + sum(lights(p)) in list order, then (x) reflectiveness of element k
 __device__ __forceinline__ void shade(const RenderArgs& A, bool active, int k, float px, float py, float pz, float& cr, float& cg, float& cb)
 {
-    const bool shadows = (A.flags & RT_SHADOWS) != 0u;
     for (int l = 0; l < A.n_lights; ++l) {
         const float4 lp = A.lpos[l];
         const float4 lc = A.lcol[l];
@@ -137,11 +119,7 @@ __device__ __forceinline__ void shade(const RenderArgs& A, bool active, int k, f
             float vx = px - lp.x, vy = py - lp.y, vz = pz - lp.z;
             float dist = sqrtf(dot3_ref(vx, vy, vz, vx, vy, vz));
             float in = lp.w / (dist * dist);
-            bool some = !(in <= 1.1920929e-7f);
-            if (shadows) {
-                bool occ = occluded(A, active && some, px, py, pz, lp.x, lp.y, lp.z);
-                some = some && !occ;
-            }
+            const bool some = !(in <= 1.1920929e-7f);
             if (some) {
                 cr = cr + in * lc.x;
                 cg = cg + in * lc.y;
@@ -155,15 +133,101 @@ __device__ __forceinline__ void shade(const RenderArgs& A, bool active, int k, f
     cb = cb * rf.z;
 }
 
-// Closest hit for a general-origin ray (bounces): exact brute force over the list in order.
-__device__ __forceinline__ void closest_general(const RenderArgs& A, bool active, float ox, float oy, float oz, float dx, float dy, float dz, float& best_t, int& best_i)
+// ---- general-origin rays (bounces, shadow rays) --------------------------------------------------------------------------
+// Conservative filter for a ray (o, u) against sphere (c, r), the reference's own formula (sphere.rs:27-29) evaluated
+// with FMAs and a relative safety margin eta = 2^-17 folded into the operands:
+//     q = o - c ;  a' = u'.q  (u' = u (1 + 2^-16)) ;  W = |q|^2 - rho  (rho = r^2 (1+eta)/(1-eta), host) ;  g = a'^2 - W
+// A reference hit needs delta = fl(alpha^2) - fl(|q|^2 - r^2) >= 0; fused and unfused evaluation of that expression differ by
+// < 48 u (|q|^2 + r^2) (u = 2^-24), so g >= 0 whenever the reference's delta >= 0.  10 FMA-class ops per (ray, sphere).
+constexpr float kGenDirScale = 1.0f + 1.52587890625e-05f;  // 1 + 2^-16
+constexpr int kGenBlock = 4;                               // spheres per wave vote in the general loops
+
+template <int P>
+__device__ __forceinline__ float general_filter(int p, const float (&ox)[P], const float (&oy)[P], const float (&oz)[P], const float (&fx)[P],
+                                                const float (&fy)[P], const float (&fz)[P], float cx, float cy, float cz, float nrho)
 {
-    best_i = -1;
-    best_t = 0.0f;
-    for (int k = 0; k < A.n; ++k) {
-        float t;
-        bool h = hit_general_exact(ox, oy, oz, dx, dy, dz, A.sph_r[k], t);
-        take_closest(active && h, t, k, best_t, best_i);
+    const float qx = ox[p] - cx, qy = oy[p] - cy, qz = oz[p] - cz;
+    const float a = __builtin_fmaf(fx[p], qx, __builtin_fmaf(fy[p], qy, fz[p] * qz));
+    const float w = __builtin_fmaf(qx, qx, __builtin_fmaf(qy, qy, __builtin_fmaf(qz, qz, nrho)));
+    return __builtin_fmaf(a, a, -w);
+}
+
+// P rays per lane against the whole list, sphere data staged per 1024-chunk in LDS (s_gen: cx | cy | cz | -rho).
+// ANY_HIT = false: closest hit (renderer.rs:47-54) -> best_t/best_i.   ANY_HIT = true (RT_SHADOWS extension): bit p of `occ`
+// is set iff some element returns t with RT_SHADOW_EPS < t < tmax[p]; a wave leaves the sphere loop once all its rays are decided.
+// Must be called by every wave of the workgroup (it contains workgroup barriers); `need` selects the live rays of this lane.
+template <int P, bool ANY_HIT>
+__device__ __forceinline__ void trace_general(const RenderArgs& A, float* s_gen, int tid, uint32_t need, const float (&ox)[P], const float (&oy)[P],
+                                              const float (&oz)[P], const float (&ux)[P], const float (&uy)[P], const float (&uz)[P],
+                                              const float (&tmax)[P], uint32_t& occ, float (&best_t)[P], int (&best_i)[P])
+{
+    float fx[P], fy[P], fz[P], gx[P], gy[P], gz[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const bool on = (need >> p) & 1u;
+        // dead rays get an inert filter: direction 0 and an origin 1e18 away => g = -|q|^2 < 0, never a candidate
+        fx[p] = on ? ux[p] * kGenDirScale : 0.0f;
+        fy[p] = on ? uy[p] * kGenDirScale : 0.0f;
+        fz[p] = on ? uz[p] * kGenDirScale : 0.0f;
+        gx[p] = on ? ox[p] : 1.0e18f;
+        gy[p] = on ? oy[p] : 1.0e18f;
+        gz[p] = on ? oz[p] : 1.0e18f;
+        if (!ANY_HIT) {
+            best_i[p] = -1;
+            best_t[p] = 0.0f;
+        }
+    }
+    occ = 0u;
+    uint32_t open = need;
+    for (int c0 = 0; c0 < A.n_pad; c0 += kChunk) {
+        const int cn = min(kChunk, A.n_pad - c0);
+        __syncthreads();
+        for (int i = tid; i < cn; i += kWaves * 64) {
+            const float4 g = A.gen[c0 + i];
+            s_gen[i] = g.x;
+            s_gen[kChunk + i] = g.y;
+            s_gen[2 * kChunk + i] = g.z;
+            s_gen[3 * kChunk + i] = g.w;
+        }
+        __syncthreads();
+        if (__builtin_amdgcn_ballot_w64(open != 0u) == 0ull) continue;  // nothing left to decide in this wave (barriers above still run)
+        for (int s0 = 0; s0 < cn; s0 += kGenBlock) {
+            const float4 vx = *reinterpret_cast<const float4*>(&s_gen[s0]);
+            const float4 vy = *reinterpret_cast<const float4*>(&s_gen[kChunk + s0]);
+            const float4 vz = *reinterpret_cast<const float4*>(&s_gen[2 * kChunk + s0]);
+            const float4 vw = *reinterpret_cast<const float4*>(&s_gen[3 * kChunk + s0]);
+            const float bx[4] = {vx.x, vx.y, vx.z, vx.w}, by[4] = {vy.x, vy.y, vy.z, vy.w}, bz[4] = {vz.x, vz.y, vz.z, vz.w},
+                        bw[4] = {vw.x, vw.y, vw.z, vw.w};
+            float m = -1.0f;
+#pragma unroll
+            for (int b = 0; b < kGenBlock; ++b)
+#pragma unroll
+                for (int p = 0; p < P; ++p) m = __builtin_fmaxf(m, general_filter<P>(p, gx, gy, gz, fx, fy, fz, bx[b], by[b], bz[b], bw[b]));
+            if (__builtin_amdgcn_ballot_w64(m >= 0.0f) == 0ull) continue;
+            for (int b = 0; b < kGenBlock; ++b) {
+                const int k = c0 + s0 + b;
+                const float4 g = A.gen[k];
+                bool cand = false;
+#pragma unroll
+                for (int p = 0; p < P; ++p) cand = cand || (general_filter<P>(p, gx, gy, gz, fx, fy, fz, g.x, g.y, g.z, g.w) >= 0.0f);
+                if (__builtin_amdgcn_ballot_w64(cand) == 0ull) continue;
+                const float4 s = A.sph_r[k];
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    float t;
+                    const bool h = hit_general_exact(ox[p], oy[p], oz[p], ux[p], uy[p], uz[p], s, t) && ((need >> p) & 1u);
+                    if (ANY_HIT) {
+                        if (h && t > RT_SHADOW_EPS && t < tmax[p]) occ |= 1u << p;
+                    } else {
+                        take_closest(h, t, k, best_t[p], best_i[p]);
+                    }
+                }
+            }
+            if (ANY_HIT) {
+                open = need & ~occ;
+                if (__builtin_amdgcn_ballot_w64(open != 0u) == 0ull) break;  // early-out: every shadow ray of this wave is blocked
+            }
+        }
     }
 }
 
@@ -171,8 +235,12 @@ template <int PX, int PY, int B, bool GENERAL>
 __global__ __launch_bounds__(kWaves * 64) void render_kernel(const RenderArgs A)
 {
     constexpr int P = PX * PY;
-    // filter constants of the current chunk, SoA so that four spheres' x (y, z) come back in one broadcast ds_read_b128
-    __shared__ __attribute__((aligned(16))) float s_x[kChunk], s_y[kChunk], s_z[kChunk];
+    // sphere constants of the current chunk, SoA so that four spheres' x (y, z) come back in one broadcast ds_read_b128;
+    // the general loops reuse the same storage with a fourth plane
+    __shared__ __attribute__((aligned(16))) float s_buf[(GENERAL ? 4 : 3) * kChunk];
+    float* const s_x = s_buf;
+    float* const s_y = s_buf + kChunk;
+    float* const s_z = s_buf + 2 * kChunk;
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
@@ -279,62 +347,138 @@ __global__ __launch_bounds__(kWaves * 64) void render_kernel(const RenderArgs A)
     }
 
     // ---- shading, bounces, store ----
+    float cr[P], cg[P], cb[P];
+    int first_hit[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        const bool in_frame = (inb >> p) & 1u;
-        const uint32_t x = x_base + kLX * (p % PX);
-        const uint32_t y = y_base + kLY * (p / PX);
-        float cr = 0.0f, cg = 0.0f, cb = 0.0f;
-        int k = best_i[p];
-        float t = best_t[p];
-        const int first_hit = k;
-        float ox = 0.0f, oy = 0.0f, oz = 0.0f;
-        float rdx = dx[p], rdy = dy[p], rdz = dz[p];
-        if (!GENERAL) {
-            const bool hit = k >= 0;
-            // renderer.rs:57, object/mod.rs:61-63 — origin + t * direction
-            float px = ox + t * rdx, py = oy + t * rdy, pz = oz + t * rdz;
+        cr[p] = cg[p] = cb[p] = 0.0f;
+        first_hit[p] = best_i[p];
+    }
+    if (!GENERAL) {
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const bool hit = best_i[p] >= 0;
+            // renderer.rs:57, object/mod.rs:61-63 — origin + t * direction (origin = 0)
+            const float px = 0.0f + best_t[p] * dx[p], py = 0.0f + best_t[p] * dy[p], pz = 0.0f + best_t[p] * dz[p];
             float r = 0.0f, g = 0.0f, b = 0.0f;
-            shade(A, hit, k, px, py, pz, r, g, b);
-            if (hit) { cr = r; cg = g; cb = b; }
-        } else {
-            bool alive = true;
-            for (uint32_t it = 0; it < A.depth; ++it) {
-                if (it > 0) closest_general(A, alive, ox, oy, oz, rdx, rdy, rdz, t, k);
-                alive = alive && (k >= 0);  // a miss leaves prev_info untouched: all later iterations miss identically
-                if (__builtin_amdgcn_ballot_w64(alive) == 0ull) break;
-                float px = ox + t * rdx, py = oy + t * rdy, pz = oz + t * rdz;
-                float r = cr, g = cg, b = cb;  // renderer.rs:59
-                shade(A, alive, k, px, py, pz, r, g, b);
-                if (alive) { cr = r; cg = g; cb = b; }
-                if (it + 1u < A.depth) {  // renderer.rs:67 (i < limit)
-                    const float4 s = A.sph_r[alive ? k : 0];
-                    float nx = ox - s.x, ny = oy - s.y, nz = oz - s.z;  // renderer.rs:68 — normal at the OLD origin
+            shade(A, hit, best_i[p], px, py, pz, r, g, b);
+            if (hit) { cr[p] = r; cg[p] = g; cb[p] = b; }
+        }
+    } else {
+        const bool shadows = (A.flags & RT_SHADOWS) != 0u;
+        float ox[P], oy[P], oz[P], hx[P], hy[P], hz[P];
+        uint32_t alive = (1u << P) - 1u;
+#pragma unroll
+        for (int p = 0; p < P; ++p) ox[p] = oy[p] = oz[p] = 0.0f;
+        // every loop below is uniform over the workgroup: trace_general() contains barriers
+        for (uint32_t it = 0; it < A.depth; ++it) {
+            if (it > 0) {
+                float no_tmax[P] = {};
+                uint32_t unused;
+                trace_general<P, false>(A, s_buf, tid, alive, ox, oy, oz, dx, dy, dz, no_tmax, unused, best_t, best_i);
+            }
+            float lr[P], lg[P], lb[P];
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                if (best_i[p] < 0) alive &= ~(1u << p);  // a miss leaves prev_info untouched: every later iteration misses identically
+                hx[p] = ox[p] + best_t[p] * dx[p];       // renderer.rs:57
+                hy[p] = oy[p] + best_t[p] * dy[p];
+                hz[p] = oz[p] + best_t[p] * dz[p];
+                lr[p] = cr[p];                           // renderer.rs:59
+                lg[p] = cg[p];
+                lb[p] = cb[p];
+            }
+            for (int l = 0; l < A.n_lights; ++l) {  // renderer.rs:60-64, list order
+                const float4 lp = A.lpos[l];
+                const float4 lc = A.lcol[l];
+                if (lc.w != 0.0f) {  // light/ambient.rs:23-25
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
+                        lr[p] = lr[p] + lc.x;
+                        lg[p] = lg[p] + lc.y;
+                        lb[p] = lb[p] + lc.z;
+                    }
+                    continue;
+                }
+                float in[P];
+                uint32_t some = 0u;
+#pragma unroll
+                for (int p = 0; p < P; ++p) {  // light/point.rs:25-30
+                    const float vx = hx[p] - lp.x, vy = hy[p] - lp.y, vz = hz[p] - lp.z;
+                    const float dist = sqrtf(dot3_ref(vx, vy, vz, vx, vy, vz));
+                    in[p] = lp.w / (dist * dist);
+                    if (!(in[p] <= 1.1920929e-7f)) some |= 1u << p;
+                }
+                if (shadows) {  // EXTENSION: occlusion toward the light, semantics of the oracle's occluded()
+                    float sx[P], sy[P], sz[P], sd[P];
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
+                        const float vx = lp.x - hx[p], vy = lp.y - hy[p], vz = lp.z - hz[p];
+                        sd[p] = sqrtf(dot3_ref(vx, vy, vz, vx, vy, vz));
+                        sx[p] = vx / sd[p];
+                        sy[p] = vy / sd[p];
+                        sz[p] = vz / sd[p];
+                    }
+                    uint32_t occ;
+                    float bt[P];
+                    int bi[P];
+                    trace_general<P, true>(A, s_buf, tid, alive & some, hx, hy, hz, sx, sy, sz, sd, occ, bt, bi);
+                    some &= ~occ;
+                }
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    if ((some >> p) & 1u) {
+                        lr[p] = lr[p] + in[p] * lc.x;
+                        lg[p] = lg[p] + in[p] * lc.y;
+                        lb[p] = lb[p] + in[p] * lc.z;
+                    }
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const bool on = (alive >> p) & 1u;
+                const float4 rf = A.refl[on ? best_i[p] : 0];
+                if (on) {  // renderer.rs:66
+                    cr[p] = lr[p] * rf.x;
+                    cg[p] = lg[p] * rf.y;
+                    cb[p] = lb[p] * rf.z;
+                }
+            }
+            if (it + 1u < A.depth) {  // renderer.rs:67 (i < limit)
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const bool on = (alive >> p) & 1u;
+                    const float4 s = A.sph_r[on ? best_i[p] : 0];
+                    float nx = ox[p] - s.x, ny = oy[p] - s.y, nz = oz[p] - s.z;  // renderer.rs:68 — normal at the OLD origin
                     unit3(nx, ny, nz);
-                    float dn = dot3_ref(rdx, rdy, rdz, nx, ny, nz);  // object/mod.rs:72
-                    float two_dn = 2.0f * dn;
-                    float ex = rdx - two_dn * nx, ey = rdy - two_dn * ny, ez = rdz - two_dn * nz;
+                    const float dn = dot3_ref(dx[p], dy[p], dz[p], nx, ny, nz);  // object/mod.rs:72
+                    const float two_dn = 2.0f * dn;
+                    float ex = dx[p] - two_dn * nx, ey = dy[p] - two_dn * ny, ez = dz[p] - two_dn * nz;
                     unit3(ex, ey, ez);
-                    if (alive) {
-                        rdx = ex; rdy = ey; rdz = ez;
-                        ox = px; oy = py; oz = pz;
+                    if (on) {
+                        dx[p] = ex; dy[p] = ey; dz[p] = ez;
+                        ox[p] = hx[p]; oy[p] = hy[p]; oz[p] = hz[p];  // renderer.rs:70
                     }
                 }
             }
         }
-        if (in_frame) {
-            const size_t pix = (size_t)(y - A.y0) * A.w + x;
-            const uint32_t r8 = quantise(cr), g8 = quantise(cg), b8 = quantise(cb);
-            if (A.flags & RT_OUT_RGB8) {
-                uint8_t* o = A.out + pix * 3;
-                o[0] = (uint8_t)r8;
-                o[1] = (uint8_t)g8;
-                o[2] = (uint8_t)b8;
-            } else {
-                reinterpret_cast<uint32_t*>(A.out)[pix] = r8 | (g8 << 8) | (b8 << 16) | 0xff000000u;
-            }
-            if (A.hit_idx) A.hit_idx[pix] = first_hit;
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        if (!((inb >> p) & 1u)) continue;
+        const uint32_t x = x_base + kLX * (p % PX);
+        const uint32_t y = y_base + kLY * (p / PX);
+        const size_t pix = (size_t)(y - A.y0) * A.w + x;
+        const uint32_t r8 = quantise(cr[p]), g8 = quantise(cg[p]), b8 = quantise(cb[p]);
+        if (A.flags & RT_OUT_RGB8) {
+            uint8_t* o = A.out + pix * 3;
+            o[0] = (uint8_t)r8;
+            o[1] = (uint8_t)g8;
+            o[2] = (uint8_t)b8;
+        } else {
+            reinterpret_cast<uint32_t*>(A.out)[pix] = r8 | (g8 << 8) | (b8 << 16) | 0xff000000u;
         }
+        if (A.hit_idx) A.hit_idx[pix] = first_hit[p];
     }
 }
 

@@ -25,7 +25,7 @@ struct rt_ctx {
     int32_t n = 0, n_pad = 0, n_always = 0, n_lights = 0;
     void* d_scene = nullptr;  // one allocation, sub-arrays below point into it
     size_t scene_bytes = 0;
-    const float4 *d_filt = nullptr, *d_sph = nullptr, *d_sph_r = nullptr, *d_refl = nullptr, *d_lpos = nullptr, *d_lcol = nullptr;
+    const float4 *d_filt = nullptr, *d_sph = nullptr, *d_sph_r = nullptr, *d_gen = nullptr, *d_refl = nullptr, *d_lpos = nullptr, *d_lcol = nullptr;
     const int32_t* d_always = nullptr;
     // staging for the host-output entry points
     void* d_out = nullptr;
@@ -137,15 +137,16 @@ int32_t rt_scene_upload(rt_ctx* c, const rt_objects* o, const rt_lights* l)
     if (!msg.empty()) return fail(c, RT_ERR_INVALID, "rt_scene_upload: " + msg);
     RT_HIP(c, hipSetDevice(c->device));
 
-    // one packed allocation: filt | sph | sph_r | refl | lpos | lcol | always   (all 16-byte aligned)
+    // one packed allocation: filt | sph | sph_r | gen | refl | lpos | lcol | always   (all 16-byte aligned)
     const size_t np = (size_t)ps.n_pad, nl = (size_t)ps.n_lights, na = ps.always.size();
-    const size_t off_filt = 0, off_sph = off_filt + np * 16, off_sph_r = off_sph + np * 16, off_refl = off_sph_r + np * 16;
+    const size_t off_filt = 0, off_sph = off_filt + np * 16, off_sph_r = off_sph + np * 16, off_gen = off_sph_r + np * 16, off_refl = off_gen + np * 16;
     const size_t off_lpos = off_refl + np * 16, off_lcol = off_lpos + (nl ? nl : 1) * 16, off_alw = off_lcol + (nl ? nl : 1) * 16;
     const size_t total = off_alw + ((na ? na : 1) * 4 + 15) / 16 * 16;
     std::vector<unsigned char> host(total, 0);
     std::memcpy(host.data() + off_filt, ps.filt.data(), np * 16);
     std::memcpy(host.data() + off_sph, ps.sph.data(), np * 16);
     std::memcpy(host.data() + off_sph_r, ps.sph_r.data(), np * 16);
+    std::memcpy(host.data() + off_gen, ps.gen.data(), np * 16);
     std::memcpy(host.data() + off_refl, ps.refl.data(), np * 16);
     if (nl) std::memcpy(host.data() + off_lpos, ps.lpos.data(), nl * 16);
     if (nl) std::memcpy(host.data() + off_lcol, ps.lcol.data(), nl * 16);
@@ -166,6 +167,7 @@ int32_t rt_scene_upload(rt_ctx* c, const rt_objects* o, const rt_lights* l)
     c->d_filt = reinterpret_cast<const float4*>(base + off_filt);
     c->d_sph = reinterpret_cast<const float4*>(base + off_sph);
     c->d_sph_r = reinterpret_cast<const float4*>(base + off_sph_r);
+    c->d_gen = reinterpret_cast<const float4*>(base + off_gen);
     c->d_refl = reinterpret_cast<const float4*>(base + off_refl);
     c->d_lpos = reinterpret_cast<const float4*>(base + off_lpos);
     c->d_lcol = reinterpret_cast<const float4*>(base + off_lcol);
@@ -203,7 +205,7 @@ int32_t rt_render_rows_device(rt_ctx* c, const float m[16], uint32_t w, uint32_t
     std::memcpy(a.m, m, sizeof(a.m));
     a.w = w; a.h = h; a.y0 = y0; a.y1 = y1; a.depth = depth; a.flags = flags;
     a.n = c->n; a.n_pad = c->n_pad; a.n_always = c->n_always; a.n_lights = c->n_lights;
-    a.filt = c->d_filt; a.sph = c->d_sph; a.sph_r = c->d_sph_r; a.refl = c->d_refl; a.always = c->d_always; a.lpos = c->d_lpos; a.lcol = c->d_lcol;
+    a.filt = c->d_filt; a.sph = c->d_sph; a.sph_r = c->d_sph_r; a.gen = c->d_gen; a.refl = c->d_refl; a.always = c->d_always; a.lpos = c->d_lpos; a.lcol = c->d_lcol;
     a.out = static_cast<uint8_t*>(d_out);
     a.hit_idx = static_cast<int32_t*>(d_hit_idx);
     RT_HIP(c, hipEventRecord(c->ev0, st));

@@ -74,6 +74,7 @@ std::string prepare_scene(const rt_objects* o, const rt_lights* l, PreparedScene
     out.filt.assign(out.n_pad, f4{0, 0, 0, 0});
     out.sph.assign(out.n_pad, f4{0, 0, 0, inf});
     out.sph_r.assign(out.n_pad, f4{0, 0, 0, NAN});
+    out.gen.assign(out.n_pad, f4{0, 0, 0, inf});  // -rho = +inf: W = +inf, g = -inf, never a candidate
     out.refl.assign(out.n_pad, f4{0, 0, 0, 0});
     out.cls.assign(o->n, 0);
     std::vector<float> k(o->n);
@@ -81,6 +82,14 @@ std::string prepare_scene(const rt_objects* o, const rt_lights* l, PreparedScene
     for (int32_t i = 0; i < o->n; ++i) {
         out.sph[i] = f4{o->cx[i], o->cy[i], o->cz[i], k[i]};
         out.sph_r[i] = f4{o->cx[i], o->cy[i], o->cz[i], o->radius[i]};
+        {
+            // general-origin filter (render_kernels.hip): rho = fl(r*r) (1+eta)/(1-eta), eta = 2^-17, rounded up
+            const double eta = std::ldexp(1.0, -17);
+            const float r2 = o->radius[i] * o->radius[i];  // the reference's own rounded r*r (sphere.rs:29)
+            float rho = (float)((double)r2 * (1.0 + eta) / (1.0 - eta));
+            rho = std::nextafter(rho, INFINITY);
+            out.gen[i] = f4{o->cx[i], o->cy[i], o->cz[i], -rho};
+        }
         out.refl[i] = f4{o->refl_r[i], o->refl_g[i], o->refl_b[i], 0.0f};
         if (!out.cls[i]) out.always.push_back(i);
     }

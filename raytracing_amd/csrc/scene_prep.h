@@ -22,6 +22,7 @@ struct PreparedScene {
     std::vector<f4> filt;        // n_pad: (cx', cy', cz', 0) — conservative primary-ray filter d.c' - 1 >= 0 ; (0,0,0,0) = never passes
     std::vector<f4> sph;         // n_pad: (cx, cy, cz, k) with k = dot3(c,c) - r*r in the reference's order (sphere.rs:29 with origin 0)
     std::vector<f4> sph_r;       // n_pad: (cx, cy, cz, radius) for general-origin rays (bounces, shadow rays)
+    std::vector<f4> gen;         // n_pad: (cx, cy, cz, -rho), rho = r*r (1+eta)/(1-eta) rounded up: general-origin filter
     std::vector<f4> refl;        // n_pad: Material.reflectiveness (element.rs:18), w unused
     std::vector<int32_t> always; // indices of spheres the filter cannot cover (origin inside / on / absurd values): tested exactly for every pixel
     std::vector<uint8_t> cls;    // n: 1 = filterable, 0 = always
