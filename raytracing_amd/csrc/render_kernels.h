@@ -23,10 +23,18 @@ struct RenderArgs {
     const float4* lcol;     // n_lights
     uint8_t* out;           // band rows, 4 or 3 B/pixel
     int32_t* hit_idx;       // nullable
+    // dense hit records (library-owned scratch, only for depth > 1 or RT_SHADOWS): one counter + capacity >= band pixels
+    uint32_t* rec_count;
+    uint32_t* rec_pix;
+    int32_t* rec_idx;
+    float* rec_t;
 };
 
 // Enqueue the render of args.[y0,y1) on `stream`. Returns the HIP status of the launch.
 hipError_t launch_render(const RenderArgs& args, hipStream_t stream);
+
+// True if launch_render needs the rec_* scratch buffers for these args (depth > 1 or RT_SHADOWS).
+bool render_needs_records(const RenderArgs& args);
 
 // Name of the kernel variant launch_render picks for these args (for profiles / bench output).
 const char* render_kernel_name(const RenderArgs& args);

@@ -231,16 +231,41 @@ __device__ __forceinline__ void trace_general(const RenderArgs& A, float* s_gen,
     }
 }
 
-template <int PX, int PY, int B, bool GENERAL>
+// display.rs:98-100 + renderer.rs:43 — primary ray direction of pixel (x = column j, y = row i): exact reference arithmetic
+__device__ __forceinline__ void primary_dir(const RenderArgs& A, uint32_t x, uint32_t y, float& dx, float& dy, float& dz)
+{
+    const float v0 = 2.0f * ((float)x / (float)A.w) - 1.0f;
+    const float v1 = 2.0f * ((float)y / (float)A.h) - 1.0f;
+    const float v2 = 2.0f * (1.0f / 1.0f) - 1.0f;
+    const float v3 = v2;
+    dx = dot4_ref(A.m + 0, v0, v1, v2, v3);
+    dy = dot4_ref(A.m + 4, v0, v1, v2, v3);
+    dz = dot4_ref(A.m + 8, v0, v1, v2, v3);
+    unit3(dx, dy, dz);
+}
+
+__device__ __forceinline__ void store_pixel(const RenderArgs& A, size_t pix, float cr, float cg, float cb)
+{
+    const uint32_t r8 = quantise(cr), g8 = quantise(cg), b8 = quantise(cb);
+    if (A.flags & RT_OUT_RGB8) {
+        uint8_t* o = A.out + pix * 3;
+        o[0] = (uint8_t)r8;
+        o[1] = (uint8_t)g8;
+        o[2] = (uint8_t)b8;
+    } else {
+        reinterpret_cast<uint32_t*>(A.out)[pix] = r8 | (g8 << 8) | (b8 << 16) | 0xff000000u;
+    }
+}
+
+// Primary rays: closest hit over the whole list.  EMIT = false: shade (depth 1, no shadows) and store the pixel — the whole
+// reference path in one launch.  EMIT = true: store black, and append every hit as a record (pixel, element, t) to a dense
+// list for shade_general_kernel (bounces / shadow rays then run with full lanes instead of the frame's ~20 % coverage).
+template <int PX, int PY, int B, bool EMIT>
 __global__ __launch_bounds__(kWaves * 64) void render_kernel(const RenderArgs A)
 {
     constexpr int P = PX * PY;
-    // sphere constants of the current chunk, SoA so that four spheres' x (y, z) come back in one broadcast ds_read_b128;
-    // the general loops reuse the same storage with a fourth plane
-    __shared__ __attribute__((aligned(16))) float s_buf[(GENERAL ? 4 : 3) * kChunk];
-    float* const s_x = s_buf;
-    float* const s_y = s_buf + kChunk;
-    float* const s_z = s_buf + 2 * kChunk;
+    // filter constants of the current chunk, SoA so that four spheres' x (y, z) come back in one broadcast ds_read_b128
+    __shared__ __attribute__((aligned(16))) float s_x[kChunk], s_y[kChunk], s_z[kChunk];
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
@@ -254,8 +279,7 @@ __global__ __launch_bounds__(kWaves * 64) void render_kernel(const RenderArgs A)
     int best_i[P];
     uint32_t inb = 0;
 
-    // ---- primary rays: display.rs:98-100, renderer.rs:43 ----
-    const float fw = (float)A.w, fh = (float)A.h;
+    // ---- primary rays ----
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         uint32_t x = x_base + kLX * (p % PX);
@@ -263,17 +287,7 @@ __global__ __launch_bounds__(kWaves * 64) void render_kernel(const RenderArgs A)
         if (x < A.w && y < A.y1) inb |= 1u << p;
         x = min(x, A.w - 1u);
         y = min(y, A.y1 - 1u);
-        float v0 = 2.0f * ((float)x / fw) - 1.0f;
-        float v1 = 2.0f * ((float)y / fh) - 1.0f;
-        float v2 = 2.0f * (1.0f / 1.0f) - 1.0f;
-        float v3 = v2;
-        float qx = dot4_ref(A.m + 0, v0, v1, v2, v3);
-        float qy = dot4_ref(A.m + 4, v0, v1, v2, v3);
-        float qz = dot4_ref(A.m + 8, v0, v1, v2, v3);
-        unit3(qx, qy, qz);
-        dx[p] = qx;
-        dy[p] = qy;
-        dz[p] = qz;
+        primary_dir(A, x, y, dx[p], dy[p], dz[p]);
         best_t[p] = 0.0f;
         best_i[p] = -1;
     }
@@ -346,15 +360,8 @@ __global__ __launch_bounds__(kWaves * 64) void render_kernel(const RenderArgs A)
         }
     }
 
-    // ---- shading, bounces, store ----
-    float cr[P], cg[P], cb[P];
-    int first_hit[P];
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        cr[p] = cg[p] = cb[p] = 0.0f;
-        first_hit[p] = best_i[p];
-    }
-    if (!GENERAL) {
+    if (!EMIT) {
+        // ---- shading and store (depth 1, reference semantics) ----
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             const bool hit = best_i[p] >= 0;
@@ -362,148 +369,207 @@ __global__ __launch_bounds__(kWaves * 64) void render_kernel(const RenderArgs A)
             const float px = 0.0f + best_t[p] * dx[p], py = 0.0f + best_t[p] * dy[p], pz = 0.0f + best_t[p] * dz[p];
             float r = 0.0f, g = 0.0f, b = 0.0f;
             shade(A, hit, best_i[p], px, py, pz, r, g, b);
-            if (hit) { cr[p] = r; cg[p] = g; cb[p] = b; }
+            if (!((inb >> p) & 1u)) continue;
+            const uint32_t x = x_base + kLX * (p % PX);
+            const uint32_t y = y_base + kLY * (p / PX);
+            const size_t pix = (size_t)(y - A.y0) * A.w + x;
+            store_pixel(A, pix, hit ? r : 0.0f, hit ? g : 0.0f, hit ? b : 0.0f);
+            if (A.hit_idx) A.hit_idx[pix] = best_i[p];
         }
     } else {
-        const bool shadows = (A.flags & RT_SHADOWS) != 0u;
-        float ox[P], oy[P], oz[P], hx[P], hy[P], hz[P];
-        uint32_t alive = (1u << P) - 1u;
+        // ---- black background + dense hit records: one atomic per wave, order inside the list is irrelevant to the image ----
+        uint32_t total = 0;
+        uint64_t hitmask[P];
 #pragma unroll
-        for (int p = 0; p < P; ++p) ox[p] = oy[p] = oz[p] = 0.0f;
-        // every loop below is uniform over the workgroup: trace_general() contains barriers
-        for (uint32_t it = 0; it < A.depth; ++it) {
-            if (it > 0) {
-                float no_tmax[P] = {};
-                uint32_t unused;
-                trace_general<P, false>(A, s_buf, tid, alive, ox, oy, oz, dx, dy, dz, no_tmax, unused, best_t, best_i);
-            }
-            float lr[P], lg[P], lb[P];
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                if (best_i[p] < 0) alive &= ~(1u << p);  // a miss leaves prev_info untouched: every later iteration misses identically
-                hx[p] = ox[p] + best_t[p] * dx[p];       // renderer.rs:57
-                hy[p] = oy[p] + best_t[p] * dy[p];
-                hz[p] = oz[p] + best_t[p] * dz[p];
-                lr[p] = cr[p];                           // renderer.rs:59
-                lg[p] = cg[p];
-                lb[p] = cb[p];
-            }
-            for (int l = 0; l < A.n_lights; ++l) {  // renderer.rs:60-64, list order
-                const float4 lp = A.lpos[l];
-                const float4 lc = A.lcol[l];
-                if (lc.w != 0.0f) {  // light/ambient.rs:23-25
-#pragma unroll
-                    for (int p = 0; p < P; ++p) {
-                        lr[p] = lr[p] + lc.x;
-                        lg[p] = lg[p] + lc.y;
-                        lb[p] = lb[p] + lc.z;
-                    }
-                    continue;
-                }
-                float in[P];
-                uint32_t some = 0u;
-#pragma unroll
-                for (int p = 0; p < P; ++p) {  // light/point.rs:25-30
-                    const float vx = hx[p] - lp.x, vy = hy[p] - lp.y, vz = hz[p] - lp.z;
-                    const float dist = sqrtf(dot3_ref(vx, vy, vz, vx, vy, vz));
-                    in[p] = lp.w / (dist * dist);
-                    if (!(in[p] <= 1.1920929e-7f)) some |= 1u << p;
-                }
-                if (shadows) {  // EXTENSION: occlusion toward the light, semantics of the oracle's occluded()
-                    float sx[P], sy[P], sz[P], sd[P];
-#pragma unroll
-                    for (int p = 0; p < P; ++p) {
-                        const float vx = lp.x - hx[p], vy = lp.y - hy[p], vz = lp.z - hz[p];
-                        sd[p] = sqrtf(dot3_ref(vx, vy, vz, vx, vy, vz));
-                        sx[p] = vx / sd[p];
-                        sy[p] = vy / sd[p];
-                        sz[p] = vz / sd[p];
-                    }
-                    uint32_t occ;
-                    float bt[P];
-                    int bi[P];
-                    trace_general<P, true>(A, s_buf, tid, alive & some, hx, hy, hz, sx, sy, sz, sd, occ, bt, bi);
-                    some &= ~occ;
-                }
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    if ((some >> p) & 1u) {
-                        lr[p] = lr[p] + in[p] * lc.x;
-                        lg[p] = lg[p] + in[p] * lc.y;
-                        lb[p] = lb[p] + in[p] * lc.z;
-                    }
-                }
-            }
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                const bool on = (alive >> p) & 1u;
-                const float4 rf = A.refl[on ? best_i[p] : 0];
-                if (on) {  // renderer.rs:66
-                    cr[p] = lr[p] * rf.x;
-                    cg[p] = lg[p] * rf.y;
-                    cb[p] = lb[p] * rf.z;
-                }
-            }
-            if (it + 1u < A.depth) {  // renderer.rs:67 (i < limit)
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    const bool on = (alive >> p) & 1u;
-                    const float4 s = A.sph_r[on ? best_i[p] : 0];
-                    float nx = ox[p] - s.x, ny = oy[p] - s.y, nz = oz[p] - s.z;  // renderer.rs:68 — normal at the OLD origin
-                    unit3(nx, ny, nz);
-                    const float dn = dot3_ref(dx[p], dy[p], dz[p], nx, ny, nz);  // object/mod.rs:72
-                    const float two_dn = 2.0f * dn;
-                    float ex = dx[p] - two_dn * nx, ey = dy[p] - two_dn * ny, ez = dz[p] - two_dn * nz;
-                    unit3(ex, ey, ez);
-                    if (on) {
-                        dx[p] = ex; dy[p] = ey; dz[p] = ez;
-                        ox[p] = hx[p]; oy[p] = hy[p]; oz[p] = hz[p];  // renderer.rs:70
-                    }
-                }
-            }
+        for (int p = 0; p < P; ++p) {
+            hitmask[p] = __builtin_amdgcn_ballot_w64(((inb >> p) & 1u) && best_i[p] >= 0);
+            total += (uint32_t)__builtin_popcountll(hitmask[p]);
         }
-    }
+        uint32_t base = 0;
+        if (lane == 0 && total) base = atomicAdd(A.rec_count, total);
+        base = __builtin_amdgcn_readfirstlane(base);
+        uint32_t off = base;
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-        if (!((inb >> p) & 1u)) continue;
-        const uint32_t x = x_base + kLX * (p % PX);
-        const uint32_t y = y_base + kLY * (p / PX);
-        const size_t pix = (size_t)(y - A.y0) * A.w + x;
-        const uint32_t r8 = quantise(cr[p]), g8 = quantise(cg[p]), b8 = quantise(cb[p]);
-        if (A.flags & RT_OUT_RGB8) {
-            uint8_t* o = A.out + pix * 3;
-            o[0] = (uint8_t)r8;
-            o[1] = (uint8_t)g8;
-            o[2] = (uint8_t)b8;
-        } else {
-            reinterpret_cast<uint32_t*>(A.out)[pix] = r8 | (g8 << 8) | (b8 << 16) | 0xff000000u;
+        for (int p = 0; p < P; ++p) {
+            const bool in_frame = (inb >> p) & 1u;
+            const uint32_t x = x_base + kLX * (p % PX);
+            const uint32_t y = y_base + kLY * (p / PX);
+            const size_t pix = (size_t)(y - A.y0) * A.w + x;
+            if (in_frame) {
+                store_pixel(A, pix, 0.0f, 0.0f, 0.0f);
+                if (A.hit_idx) A.hit_idx[pix] = best_i[p];
+                if (best_i[p] >= 0) {
+                    const uint32_t r = off + __builtin_amdgcn_mbcnt_hi((uint32_t)(hitmask[p] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hitmask[p], 0u));
+                    A.rec_pix[r] = (uint32_t)pix;
+                    A.rec_idx[r] = best_i[p];
+                    A.rec_t[r] = best_t[p];
+                }
+            }
+            off += (uint32_t)__builtin_popcountll(hitmask[p]);
         }
-        if (A.hit_idx) A.hit_idx[pix] = first_hit[p];
     }
 }
 
-template <int PX, int PY, int B, bool GENERAL>
-hipError_t launch_variant(const RenderArgs& args, hipStream_t stream)
+// Bounces (renderer.rs:46-73 for i >= 1) and RT_SHADOWS for the hit records emitted by render_kernel<EMIT>.  A wave owns
+// 64*P consecutive records (they come from neighbouring pixels, so the wave votes of trace_general stay effective).
+template <int P>
+__global__ __launch_bounds__(kWaves * 64) void shade_general_kernel(const RenderArgs A)
 {
-    const uint32_t rows = args.y1 - args.y0;
-    dim3 grid((args.w + kWaves * kLX * PX - 1) / (kWaves * kLX * PX), (rows + kLY * PY - 1) / (kLY * PY));
-    hipLaunchKernelGGL((render_kernel<PX, PY, B, GENERAL>), grid, dim3(kWaves * 64), 0, stream, args);
-    return hipGetLastError();
+    __shared__ __attribute__((aligned(16))) float s_buf[4 * kChunk];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const uint32_t count = *A.rec_count;
+    const uint32_t wg_first = blockIdx.x * (kWaves * 64 * P);
+    if (wg_first >= count) return;  // whole workgroup: no barrier has been executed yet
+    const uint32_t wave_first = wg_first + wave * (64 * P);
+
+    const bool shadows = (A.flags & RT_SHADOWS) != 0u;
+    float dx[P], dy[P], dz[P], best_t[P], cr[P], cg[P], cb[P], ox[P], oy[P], oz[P], hx[P], hy[P], hz[P];
+    int best_i[P];
+    uint32_t pix[P];
+    uint32_t alive = 0u, valid = 0u;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const uint32_t r = wave_first + p * 64 + lane;
+        const bool ok = r < count;
+        pix[p] = ok ? A.rec_pix[r] : 0u;
+        best_i[p] = ok ? A.rec_idx[r] : -1;
+        best_t[p] = ok ? A.rec_t[r] : 0.0f;
+        if (ok) valid |= 1u << p;
+        const uint32_t y = A.y0 + pix[p] / A.w, x = pix[p] % A.w;
+        primary_dir(A, x, y, dx[p], dy[p], dz[p]);
+        cr[p] = cg[p] = cb[p] = 0.0f;
+        ox[p] = oy[p] = oz[p] = 0.0f;
+    }
+    alive = valid;
+    // every loop below is uniform over the workgroup: trace_general() contains barriers
+    for (uint32_t it = 0; it < A.depth; ++it) {
+        if (it > 0) {
+            float no_tmax[P] = {};
+            uint32_t unused;
+            trace_general<P, false>(A, s_buf, tid, alive, ox, oy, oz, dx, dy, dz, no_tmax, unused, best_t, best_i);
+        }
+        float lr[P], lg[P], lb[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            if (best_i[p] < 0) alive &= ~(1u << p);  // a miss leaves prev_info untouched: every later iteration misses identically
+            hx[p] = ox[p] + best_t[p] * dx[p];       // renderer.rs:57
+            hy[p] = oy[p] + best_t[p] * dy[p];
+            hz[p] = oz[p] + best_t[p] * dz[p];
+            lr[p] = cr[p];                           // renderer.rs:59
+            lg[p] = cg[p];
+            lb[p] = cb[p];
+        }
+        for (int l = 0; l < A.n_lights; ++l) {  // renderer.rs:60-64, list order
+            const float4 lp = A.lpos[l];
+            const float4 lc = A.lcol[l];
+            if (lc.w != 0.0f) {  // light/ambient.rs:23-25
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    lr[p] = lr[p] + lc.x;
+                    lg[p] = lg[p] + lc.y;
+                    lb[p] = lb[p] + lc.z;
+                }
+                continue;
+            }
+            float in[P];
+            uint32_t some = 0u;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {  // light/point.rs:25-30
+                const float vx = hx[p] - lp.x, vy = hy[p] - lp.y, vz = hz[p] - lp.z;
+                const float dist = sqrtf(dot3_ref(vx, vy, vz, vx, vy, vz));
+                in[p] = lp.w / (dist * dist);
+                if (!(in[p] <= 1.1920929e-7f)) some |= 1u << p;
+            }
+            if (shadows) {  // EXTENSION: occlusion toward the light, semantics of the oracle's occluded()
+                float sx[P], sy[P], sz[P], sd[P];
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const float vx = lp.x - hx[p], vy = lp.y - hy[p], vz = lp.z - hz[p];
+                    sd[p] = sqrtf(dot3_ref(vx, vy, vz, vx, vy, vz));
+                    sx[p] = vx / sd[p];
+                    sy[p] = vy / sd[p];
+                    sz[p] = vz / sd[p];
+                }
+                uint32_t occ;
+                float bt[P];
+                int bi[P];
+                trace_general<P, true>(A, s_buf, tid, alive & some, hx, hy, hz, sx, sy, sz, sd, occ, bt, bi);
+                some &= ~occ;
+            }
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                if ((some >> p) & 1u) {
+                    lr[p] = lr[p] + in[p] * lc.x;
+                    lg[p] = lg[p] + in[p] * lc.y;
+                    lb[p] = lb[p] + in[p] * lc.z;
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const bool on = (alive >> p) & 1u;
+            const float4 rf = A.refl[on ? best_i[p] : 0];
+            if (on) {  // renderer.rs:66
+                cr[p] = lr[p] * rf.x;
+                cg[p] = lg[p] * rf.y;
+                cb[p] = lb[p] * rf.z;
+            }
+        }
+        if (it + 1u < A.depth) {  // renderer.rs:67 (i < limit)
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const bool on = (alive >> p) & 1u;
+                const float4 s = A.sph_r[on ? best_i[p] : 0];
+                float nx = ox[p] - s.x, ny = oy[p] - s.y, nz = oz[p] - s.z;  // renderer.rs:68 — normal at the OLD origin
+                unit3(nx, ny, nz);
+                const float dn = dot3_ref(dx[p], dy[p], dz[p], nx, ny, nz);  // object/mod.rs:72
+                const float two_dn = 2.0f * dn;
+                float ex = dx[p] - two_dn * nx, ey = dy[p] - two_dn * ny, ez = dz[p] - two_dn * nz;
+                unit3(ex, ey, ez);
+                if (on) {
+                    dx[p] = ex; dy[p] = ey; dz[p] = ez;
+                    ox[p] = hx[p]; oy[p] = hy[p]; oz[p] = hz[p];  // renderer.rs:70
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+        if ((valid >> p) & 1u) store_pixel(A, pix[p], cr[p], cg[p], cb[p]);
 }
 
 inline bool is_general(const RenderArgs& a) { return a.depth > 1u || (a.flags & RT_SHADOWS) != 0u; }
 
+constexpr int kPX = 1, kPY = 4, kB = 8;  // geometry chosen by the sweep recorded in profiles/r01_tuning.md
+constexpr int kShadeP = 2;               // records per lane in shade_general_kernel
+
 }  // namespace
 
-// Geometry chosen by the sweep recorded in profiles/r01_tuning.md: 16x4 lanes, 1x4 pixels per lane (16x16-pixel wave tile),
-// one vote per 8 spheres.
+bool render_needs_records(const RenderArgs& args) { return is_general(args); }
+
 hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
 {
     if (args.y1 <= args.y0 || args.w == 0) return hipSuccess;
-    if (is_general(args)) return launch_variant<1, 4, 8, true>(args, stream);
-    return launch_variant<1, 4, 8, false>(args, stream);
+    const uint32_t rows = args.y1 - args.y0;
+    const dim3 grid((args.w + kWaves * kLX * kPX - 1) / (kWaves * kLX * kPX), (rows + kLY * kPY - 1) / (kLY * kPY));
+    if (!is_general(args)) {
+        hipLaunchKernelGGL((render_kernel<kPX, kPY, kB, false>), grid, dim3(kWaves * 64), 0, stream, args);
+        return hipGetLastError();
+    }
+    if (!args.rec_count || !args.rec_pix || !args.rec_idx || !args.rec_t) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(args.rec_count, 0, sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((render_kernel<kPX, kPY, kB, true>), grid, dim3(kWaves * 64), 0, stream, args);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    // sized for the worst case (every pixel hit); workgroups past the record count exit at once, so no host round trip is needed
+    const uint64_t npix = (uint64_t)rows * args.w;
+    const uint32_t per_wg = kWaves * 64 * kShadeP;
+    hipLaunchKernelGGL((shade_general_kernel<kShadeP>), dim3((uint32_t)((npix + per_wg - 1) / per_wg)), dim3(kWaves * 64), 0, stream, args);
+    return hipGetLastError();
 }
 
-const char* render_kernel_name(const RenderArgs& args) { return is_general(args) ? "render_kernel<1,4,8,general>" : "render_kernel<1,4,8,primary>"; }
+const char* render_kernel_name(const RenderArgs& args) { return is_general(args) ? "render_kernel<emit> + shade_general_kernel" : "render_kernel<primary>"; }
 
 }  // namespace rtamd

@@ -32,6 +32,9 @@ struct rt_ctx {
     size_t d_out_bytes = 0;
     void* d_hit = nullptr;
     size_t d_hit_bytes = 0;
+    // dense hit records for the general path: [count (16 B) | pix | idx | t], capacity in pixels
+    void* d_rec = nullptr;
+    size_t rec_capacity = 0;
 };
 
 static thread_local std::string g_create_err;
@@ -122,6 +125,7 @@ int32_t rt_ctx_destroy(rt_ctx* c)
     if (c->d_scene) (void)hipFree(c->d_scene);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_hit) (void)hipFree(c->d_hit);
+    if (c->d_rec) (void)hipFree(c->d_rec);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -208,6 +212,23 @@ int32_t rt_render_rows_device(rt_ctx* c, const float m[16], uint32_t w, uint32_t
     a.filt = c->d_filt; a.sph = c->d_sph; a.sph_r = c->d_sph_r; a.gen = c->d_gen; a.refl = c->d_refl; a.always = c->d_always; a.lpos = c->d_lpos; a.lcol = c->d_lcol;
     a.out = static_cast<uint8_t*>(d_out);
     a.hit_idx = static_cast<int32_t*>(d_hit_idx);
+    a.rec_count = nullptr; a.rec_pix = nullptr; a.rec_idx = nullptr; a.rec_t = nullptr;
+    if (render_needs_records(a)) {
+        const size_t npix = (size_t)(y1 - y0) * w;
+        if (npix > c->rec_capacity) {  // grow the scratch (the previous launches that used it must be finished first)
+            RT_HIP(c, hipDeviceSynchronize());
+            if (c->d_rec) RT_HIP(c, hipFree(c->d_rec));
+            c->d_rec = nullptr;
+            c->rec_capacity = 0;
+            RT_HIP(c, hipMalloc(&c->d_rec, 16 + npix * 12));
+            c->rec_capacity = npix;
+        }
+        char* base = static_cast<char*>(c->d_rec);
+        a.rec_count = reinterpret_cast<uint32_t*>(base);
+        a.rec_pix = reinterpret_cast<uint32_t*>(base + 16);
+        a.rec_idx = reinterpret_cast<int32_t*>(base + 16 + c->rec_capacity * 4);
+        a.rec_t = reinterpret_cast<float*>(base + 16 + c->rec_capacity * 8);
+    }
     RT_HIP(c, hipEventRecord(c->ev0, st));
     RT_HIP(c, launch_render(a, st));
     RT_HIP(c, hipEventRecord(c->ev1, st));
