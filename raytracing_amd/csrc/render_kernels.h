@@ -21,6 +21,9 @@ struct RenderArgs {
     const int32_t* always;  // n_always
     const float4* lpos;     // n_lights
     const float4* lcol;     // n_lights
+    const float4* lfilt;        // n_lights * n_pad: per-light shadow filter constants
+    const int32_t* lalways;     // per-light always-test lists, concatenated
+    const int32_t* lalways_off; // n_lights + 1
     uint8_t* out;           // band rows, 4 or 3 B/pixel
     int32_t* hit_idx;       // nullable
     // dense hit records (library-owned scratch, only for depth > 1 or RT_SHADOWS): one counter + capacity >= band pixels

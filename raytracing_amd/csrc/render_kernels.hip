@@ -231,6 +231,86 @@ __device__ __forceinline__ void trace_general(const RenderArgs& A, float* s_gen,
     }
 }
 
+// RT_SHADOWS, one point light `l`: P shadow rays per lane (from hit point h toward lp, direction u, length sd).  Seen from the
+// light they share an origin, so the primary-ray 3-FMA filter applies with the per-light constants A.lfilt (scene_prep.cpp:
+// prepare_light_filters); candidates run the reference's exact general-origin test on the ORIGINAL ray (h, u), so the result is
+// bit-identical to the oracle's occluded().  Bit p of `occ` = ray p is blocked.  Contains workgroup barriers.
+template <int P, int B>
+__device__ __forceinline__ void trace_shadow(const RenderArgs& A, float* s_buf, int tid, int l, uint32_t need, const float (&hx)[P], const float (&hy)[P],
+                                             const float (&hz)[P], const float (&ux)[P], const float (&uy)[P], const float (&uz)[P],
+                                             const float (&sd)[P], uint32_t& occ)
+{
+    float* const s_x = s_buf;
+    float* const s_y = s_buf + kChunk;
+    float* const s_z = s_buf + 2 * kChunk;
+    float wx[P], wy[P], wz[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const bool on = (need >> p) & 1u;  // dead rays: w = 0 => f = -1, never a candidate
+        wx[p] = on ? -ux[p] : 0.0f;
+        wy[p] = on ? -uy[p] : 0.0f;
+        wz[p] = on ? -uz[p] : 0.0f;
+    }
+    occ = 0u;
+    auto exact = [&](int k) {
+        const float4 s = A.sph_r[k];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            float t;
+            const bool h = hit_general_exact(hx[p], hy[p], hz[p], ux[p], uy[p], uz[p], s, t);
+            if (h && t > RT_SHADOW_EPS && t < sd[p] && ((need >> p) & 1u)) {
+                occ |= 1u << p;
+                wx[p] = wy[p] = wz[p] = 0.0f;  // decided: stop raising candidates
+            }
+        }
+    };
+    for (int a = A.lalways_off[l]; a < A.lalways_off[l + 1]; ++a) exact(A.lalways[a]);
+    uint32_t open = need & ~occ;
+    const float4* const filt = A.lfilt + (size_t)l * A.n_pad;
+    for (int c0 = 0; c0 < A.n_pad; c0 += kChunk) {
+        const int cn = min(kChunk, A.n_pad - c0);
+        __syncthreads();
+        for (int i = tid; i < cn; i += kWaves * 64) {
+            const float4 q = filt[c0 + i];
+            s_x[i] = q.x;
+            s_y[i] = q.y;
+            s_z[i] = q.z;
+        }
+        __syncthreads();
+        if (__builtin_amdgcn_ballot_w64(open != 0u) == 0ull) continue;  // this wave is done (barriers above still run)
+        for (int s0 = 0; s0 < cn; s0 += B) {
+            float m = -1.0f;
+            float qx[B], qy[B], qz[B];
+#pragma unroll
+            for (int g = 0; g < B; g += 4) {
+                const float4 vx = *reinterpret_cast<const float4*>(&s_x[s0 + g]);
+                const float4 vy = *reinterpret_cast<const float4*>(&s_y[s0 + g]);
+                const float4 vz = *reinterpret_cast<const float4*>(&s_z[s0 + g]);
+                qx[g] = vx.x; qx[g + 1] = vx.y; qx[g + 2] = vx.z; qx[g + 3] = vx.w;
+                qy[g] = vy.x; qy[g + 1] = vy.y; qy[g + 2] = vy.z; qy[g + 3] = vy.w;
+                qz[g] = vz.x; qz[g + 1] = vz.y; qz[g + 2] = vz.z; qz[g + 3] = vz.w;
+            }
+#pragma unroll
+            for (int b = 0; b < B; ++b)
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    m = __builtin_fmaxf(m, __builtin_fmaf(wx[p], qx[b], __builtin_fmaf(wy[p], qy[b], __builtin_fmaf(wz[p], qz[b], -1.0f))));
+            if (__builtin_amdgcn_ballot_w64(m >= 0.0f) == 0ull) continue;
+            for (int b = 0; b < B; ++b) {
+                const float4 q = filt[c0 + s0 + b];
+                bool cand = false;
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    cand = cand || (__builtin_fmaf(wx[p], q.x, __builtin_fmaf(wy[p], q.y, __builtin_fmaf(wz[p], q.z, -1.0f))) >= 0.0f);
+                if (__builtin_amdgcn_ballot_w64(cand) == 0ull) continue;
+                exact(c0 + s0 + b);
+            }
+            open = need & ~occ;
+            if (__builtin_amdgcn_ballot_w64(open != 0u) == 0ull) break;  // early-out: every shadow ray of this wave is blocked
+        }
+    }
+}
+
 // display.rs:98-100 + renderer.rs:43 — primary ray direction of pixel (x = column j, y = row i): exact reference arithmetic
 __device__ __forceinline__ void primary_dir(const RenderArgs& A, uint32_t x, uint32_t y, float& dx, float& dy, float& dz)
 {
@@ -493,9 +573,7 @@ __global__ __launch_bounds__(kWaves * 64) void shade_general_kernel(const Render
                     sz[p] = vz / sd[p];
                 }
                 uint32_t occ;
-                float bt[P];
-                int bi[P];
-                trace_general<P, true>(A, s_buf, tid, alive & some, hx, hy, hz, sx, sy, sz, sd, occ, bt, bi);
+                trace_shadow<P, 8>(A, s_buf, tid, l, alive & some, hx, hy, hz, sx, sy, sz, sd, occ);
                 some &= ~occ;
             }
 #pragma unroll
@@ -543,7 +621,7 @@ __global__ __launch_bounds__(kWaves * 64) void shade_general_kernel(const Render
 inline bool is_general(const RenderArgs& a) { return a.depth > 1u || (a.flags & RT_SHADOWS) != 0u; }
 
 constexpr int kPX = 1, kPY = 4, kB = 8;  // geometry chosen by the sweep recorded in profiles/r01_tuning.md
-constexpr int kShadeP = 2;               // records per lane in shade_general_kernel
+constexpr int kShadeP = 4;               // records per lane in shade_general_kernel
 
 }  // namespace
 

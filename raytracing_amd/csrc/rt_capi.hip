@@ -27,6 +27,8 @@ struct rt_ctx {
     size_t scene_bytes = 0;
     const float4 *d_filt = nullptr, *d_sph = nullptr, *d_sph_r = nullptr, *d_gen = nullptr, *d_refl = nullptr, *d_lpos = nullptr, *d_lcol = nullptr;
     const int32_t* d_always = nullptr;
+    const float4* d_lfilt = nullptr;
+    const int32_t *d_lalways = nullptr, *d_lalways_off = nullptr;
     // staging for the host-output entry points
     void* d_out = nullptr;
     size_t d_out_bytes = 0;
@@ -141,11 +143,15 @@ int32_t rt_scene_upload(rt_ctx* c, const rt_objects* o, const rt_lights* l)
     if (!msg.empty()) return fail(c, RT_ERR_INVALID, "rt_scene_upload: " + msg);
     RT_HIP(c, hipSetDevice(c->device));
 
-    // one packed allocation: filt | sph | sph_r | gen | refl | lpos | lcol | always   (all 16-byte aligned)
+    // one packed allocation: filt | sph | sph_r | gen | refl | lpos | lcol | always | lfilt | lalways | lalways_off   (all 16-byte aligned)
     const size_t np = (size_t)ps.n_pad, nl = (size_t)ps.n_lights, na = ps.always.size();
     const size_t off_filt = 0, off_sph = off_filt + np * 16, off_sph_r = off_sph + np * 16, off_gen = off_sph_r + np * 16, off_refl = off_gen + np * 16;
     const size_t off_lpos = off_refl + np * 16, off_lcol = off_lpos + (nl ? nl : 1) * 16, off_alw = off_lcol + (nl ? nl : 1) * 16;
-    const size_t total = off_alw + ((na ? na : 1) * 4 + 15) / 16 * 16;
+    const size_t off_lfilt = off_alw + ((na ? na : 1) * 4 + 15) / 16 * 16;
+    const size_t nla = ps.lalways.size();
+    const size_t off_lalw = off_lfilt + (nl ? nl : 1) * np * 16;
+    const size_t off_laoff = off_lalw + ((nla ? nla : 1) * 4 + 15) / 16 * 16;
+    const size_t total = off_laoff + ((nl + 1) * 4 + 15) / 16 * 16;
     std::vector<unsigned char> host(total, 0);
     std::memcpy(host.data() + off_filt, ps.filt.data(), np * 16);
     std::memcpy(host.data() + off_sph, ps.sph.data(), np * 16);
@@ -155,6 +161,9 @@ int32_t rt_scene_upload(rt_ctx* c, const rt_objects* o, const rt_lights* l)
     if (nl) std::memcpy(host.data() + off_lpos, ps.lpos.data(), nl * 16);
     if (nl) std::memcpy(host.data() + off_lcol, ps.lcol.data(), nl * 16);
     if (na) std::memcpy(host.data() + off_alw, ps.always.data(), na * 4);
+    if (nl) std::memcpy(host.data() + off_lfilt, ps.lfilt.data(), nl * np * 16);
+    if (nla) std::memcpy(host.data() + off_lalw, ps.lalways.data(), nla * 4);
+    std::memcpy(host.data() + off_laoff, ps.lalways_off.data(), (nl + 1) * 4);
 
     RT_HIP(c, hipStreamSynchronize(c->stream));  // no render may still read the old scene
     if (total > c->scene_bytes) {
@@ -176,6 +185,9 @@ int32_t rt_scene_upload(rt_ctx* c, const rt_objects* o, const rt_lights* l)
     c->d_lpos = reinterpret_cast<const float4*>(base + off_lpos);
     c->d_lcol = reinterpret_cast<const float4*>(base + off_lcol);
     c->d_always = reinterpret_cast<const int32_t*>(base + off_alw);
+    c->d_lfilt = reinterpret_cast<const float4*>(base + off_lfilt);
+    c->d_lalways = reinterpret_cast<const int32_t*>(base + off_lalw);
+    c->d_lalways_off = reinterpret_cast<const int32_t*>(base + off_laoff);
     c->n = ps.n;
     c->n_pad = ps.n_pad;
     c->n_always = (int32_t)na;
@@ -209,7 +221,7 @@ int32_t rt_render_rows_device(rt_ctx* c, const float m[16], uint32_t w, uint32_t
     std::memcpy(a.m, m, sizeof(a.m));
     a.w = w; a.h = h; a.y0 = y0; a.y1 = y1; a.depth = depth; a.flags = flags;
     a.n = c->n; a.n_pad = c->n_pad; a.n_always = c->n_always; a.n_lights = c->n_lights;
-    a.filt = c->d_filt; a.sph = c->d_sph; a.sph_r = c->d_sph_r; a.gen = c->d_gen; a.refl = c->d_refl; a.always = c->d_always; a.lpos = c->d_lpos; a.lcol = c->d_lcol;
+    a.filt = c->d_filt; a.sph = c->d_sph; a.sph_r = c->d_sph_r; a.gen = c->d_gen; a.refl = c->d_refl; a.always = c->d_always; a.lpos = c->d_lpos; a.lcol = c->d_lcol; a.lfilt = c->d_lfilt; a.lalways = c->d_lalways; a.lalways_off = c->d_lalways_off;
     a.out = static_cast<uint8_t*>(d_out);
     a.hit_idx = static_cast<int32_t*>(d_hit_idx);
     a.rec_count = nullptr; a.rec_pix = nullptr; a.rec_idx = nullptr; a.rec_t = nullptr;

@@ -51,6 +51,80 @@ void prepare_filter(int32_t n, const float* cx, const float* cy, const float* cz
     }
 }
 
+/*
+ * Shadow-ray filter (RT_SHADOWS extension).  A shadow ray runs from a hit point h toward the light at lp with the float
+ * direction u = (lp - h)/dist; the kernel tests the reversed line {lp + t w}, w = -u, which has a COMMON origin for all rays
+ * of one light, so the primary-ray filter  f = w.c'' - 1 >= 0  applies with q' = c - lp.  For every (ray, sphere) the
+ * reference's exact test could accept, the filter must pass:
+ *   - the reference evaluates delta from q = h - c in f32: its delta >= 0 only guarantees dist(c, line)^2 <= r^2 + 55 u (|q|^2 + r^2);
+ *   - the reversed line is parallel to the reference's, offset by the rounding residual of u (<= 6 u dist);
+ *   - |w| = 1 +- 3u.
+ * With S >= every |q| and every dist in the scene this is covered by testing against the inflated radius
+ *   R^2 = r^2 + 128 u (S^2 + r^2)      and      mu = 20 u (1 + M/sqrt(k)),  k = |q'|^2 - R^2.
+ * Spheres with k <= 0 (the light is inside / within the noise band of the sphere), M/sqrt(k) > 2^10 or non-finite data are
+ * listed per light and tested exactly for every ray.  Candidates always go through the reference's exact test.
+ */
+static void prepare_light_filters(const rt_objects* o, const rt_lights* l, PreparedScene& out)
+{
+    const double u = std::ldexp(1.0, -24);
+    const int32_t n = o->n, nl = l->n, np = out.n_pad;
+    out.lfilt.assign((size_t)nl * np, f4{0, 0, 0, 0});
+    out.lalways.clear();
+    out.lalways_off.assign(nl + 1, 0);
+    // bounding ball of everything a ray can start from or end at: sphere surfaces, the camera (0,0,0), the lights
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    auto grow = [&](double x, double y, double z) {
+        const double v[3] = {x, y, z};
+        for (int a = 0; a < 3; ++a) {
+            if (v[a] < lo[a]) lo[a] = v[a];
+            if (v[a] > hi[a]) hi[a] = v[a];
+        }
+    };
+    std::vector<char> fin(n, 0);
+    for (int32_t i = 0; i < n; ++i) {
+        fin[i] = std::isfinite(o->cx[i]) && std::isfinite(o->cy[i]) && std::isfinite(o->cz[i]) && std::isfinite(o->radius[i]);
+        if (fin[i]) grow(o->cx[i], o->cy[i], o->cz[i]);
+    }
+    const double C[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
+    auto distC = [&](double x, double y, double z) { return std::sqrt((x - C[0]) * (x - C[0]) + (y - C[1]) * (y - C[1]) + (z - C[2]) * (z - C[2])); };
+    double Rs = distC(0, 0, 0);
+    for (int32_t i = 0; i < n; ++i)
+        if (fin[i]) Rs = std::fmax(Rs, distC(o->cx[i], o->cy[i], o->cz[i]) + std::fabs((double)o->radius[i]));
+    for (int32_t m = 0; m < nl; ++m) {
+        const uint8_t kind = l->kind ? l->kind[m] : (uint8_t)RT_POINT;
+        out.lalways_off[m] = (int32_t)out.lalways.size();
+        if (kind != RT_POINT) continue;
+        const double lx = l->px[m], ly = l->py[m], lz = l->pz[m];
+        const bool lfin = std::isfinite(lx) && std::isfinite(ly) && std::isfinite(lz);
+        const double Sl = lfin ? distC(lx, ly, lz) + Rs : 0.0;  // >= every |lp - h|
+        for (int32_t i = 0; i < n; ++i) {
+            bool ok = fin[i] && lfin;
+            double qx = 0, qy = 0, qz = 0, s = 1, M = 0;
+            if (ok) {
+                qx = o->cx[i] - lx; qy = o->cy[i] - ly; qz = o->cz[i] - lz;
+                const double r2 = (double)o->radius[i] * (double)o->radius[i];
+                const double S = 1.01 * std::fmax(distC(o->cx[i], o->cy[i], o->cz[i]) + Rs, Sl);  // >= every |h - c_i| and every dist
+                const double R2 = r2 + 128.0 * u * (S * S + r2);
+                const double k = qx * qx + qy * qy + qz * qz - R2;
+                M = std::fabs(qx) + std::fabs(qy) + std::fabs(qz);
+                ok = std::isfinite(k) && k > 0.0 && M >= 1e-12 && M <= 1e12;
+                if (ok) {
+                    s = std::sqrt(k);
+                    ok = M / s <= 1024.0;
+                }
+            }
+            if (ok) {
+                const double mu = 20.0 * u * (1.0 + M / s);
+                const double g = (1.0 + mu) / s;
+                out.lfilt[(size_t)m * np + i] = f4{(float)(qx * g), (float)(qy * g), (float)(qz * g), 0.0f};
+            } else {
+                out.lalways.push_back(i);
+            }
+        }
+    }
+    out.lalways_off[nl] = (int32_t)out.lalways.size();
+}
+
 std::string prepare_scene(const rt_objects* o, const rt_lights* l, PreparedScene& out)
 {
     if (!o || !l) return "objects/lights is null";
@@ -103,6 +177,7 @@ std::string prepare_scene(const rt_objects* o, const rt_lights* l, PreparedScene
             out.lpos[i] = f4{0, 0, 0, 0};
         out.lcol[i] = f4{l->cr[i], l->cg[i], l->cb[i], (float)kd};
     }
+    prepare_light_filters(o, l, out);
     return std::string();
 }
 

@@ -28,6 +28,11 @@ struct PreparedScene {
     std::vector<uint8_t> cls;    // n: 1 = filterable, 0 = always
     std::vector<f4> lpos;        // n_lights: (px, py, pz, intensity)
     std::vector<f4> lcol;        // n_lights: (cr, cg, cb, kind as float: 0 = point, 1 = ambient)
+    // RT_SHADOWS: per light the shadow rays share the end point lp, so seen from the light they are "primary rays" and the
+    // 3-FMA filter applies with sphere centres relative to lp and an inflated radius (scene_prep.cpp: prepare_light_filters)
+    std::vector<f4> lfilt;             // n_lights * n_pad: (c''x, c''y, c''z, 0); all zero for ambient lights
+    std::vector<int32_t> lalways;      // per light, indices of spheres its filter cannot cover (concatenated)
+    std::vector<int32_t> lalways_off;  // n_lights + 1 offsets into lalways
 };
 
 // Returns empty string on success, else an error text. Validates kinds and pointers.

@@ -208,3 +208,46 @@ def test_cpp_host_mirror_main(tmp_path):
     _assert_same(got, np.load(os.path.join(GOLDEN, "result_100x100.npy")), "C++ main result.png")
     bad = subprocess.run([os.path.abspath(exe), "10", "10", "0"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
     assert bad.returncode == 1 and "depth - 1" in bad.stderr
+
+
+def test_shadows_adversarial_lights(gpu_ctx, oracle):
+    """RT_SHADOWS with lights inside spheres, on surfaces, far outside the scene, plus ambient lights in the list; 2 chunks of spheres."""
+    w, h = 200, 112
+    objs, _ = scenegen.generate(w, h, 1300, 1, seed=33)
+    k = 7
+    f = np.float32
+    px = np.array([0.0, objs.cx[k], objs.cx[3] + objs.radius[3], 300.0, -2.0, 0.0, 1.5], f)
+    py = np.array([0.0, objs.cy[k], objs.cy[3], 200.0, 3.0, 0.0, -0.5], f)
+    pz = np.array([0.0, objs.cz[k], objs.cz[3], 100.0, -15.0, 0.0, -6.0], f)
+    kind = np.array([0, 0, 0, 0, 0, 1, 0], np.uint8)  # [1] sits at a sphere centre, [2] on a sphere surface, [3] far away, [5] ambient
+    col = np.array([1.0, 0.8, 0.6, 1.0, 0.9, 0.05, 0.7], f)
+    inten = np.array([3.0, 4.0, 2.0, 20000.0, 6.0, 0.0, 5.0], f)
+    lights = capi.FlatLights(px, py, pz, col, col[::-1].copy(), col.copy(), inten, kind=kind)
+    gpu_ctx.scene_upload(objs, lights)
+    m = _cam(oracle, w, h)
+    for depth in (1, 2):
+        gpu = gpu_ctx.render(m, w, h, depth, capi.RT_SHADOWS)
+        ref = oracle.render(objs, lights, m, w, h, depth=depth, flags=1)
+        _assert_same(gpu, ref, f"adversarial shadows depth {depth}")
+
+
+def test_c5_scene_reduced_resolution(gpu_ctx, oracle):
+    """Config 5's scene (4096 spheres, 32 lights; SCENE-GEN for 3840x2160) rendered at 320x180, shadows on and off."""
+    _, _, objs, lights = scenegen.config("C5")
+    w, h = 320, 180
+    gpu_ctx.scene_upload(objs, lights)
+    m = _cam(oracle, w, h)
+    _assert_same(gpu_ctx.render(m, w, h, 1, 0), oracle.render(objs, lights, m, w, h), "C5 scene, no shadows")
+    _assert_same(gpu_ctx.render(m, w, h, 1, capi.RT_SHADOWS), oracle.render(objs, lights, m, w, h, flags=1), "C5 scene, shadows")
+
+
+def test_c4_scene_reduced_resolution(gpu_ctx, oracle):
+    """Config 4's scene (8192 spheres = 8 LDS chunks, 8 lights) at 480x270 and as two bands."""
+    _, _, objs, lights = scenegen.config("C4")
+    w, h = 480, 270
+    gpu_ctx.scene_upload(objs, lights)
+    m = _cam(oracle, w, h)
+    ref = oracle.render(objs, lights, m, w, h)
+    _assert_same(gpu_ctx.render(m, w, h), ref, "C4 scene")
+    parts = [gpu_ctx.render_rows(m, w, h, 0, 135)[0], gpu_ctx.render_rows(m, w, h, 135, 270)[0]]
+    _assert_same(np.concatenate(parts), ref, "C4 scene bands")
