@@ -22,7 +22,8 @@ RT_SHADOWS = 1
 RT_OUT_RGB8 = 2
 RT_SHADOW_EPS = 1.0e-3
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librt_mi355x.so")
+# RT_MI355X_LIB overrides the in-tree library (used to A/B kernel builds on the GPU box)
+LIB_PATH = os.environ.get("RT_MI355X_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "librt_mi355x.so")
 
 EXPORTS = (
     "rt_version", "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_camera_transform", "rt_camera_default",

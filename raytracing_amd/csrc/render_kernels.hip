@@ -621,7 +621,7 @@ __global__ __launch_bounds__(kWaves * 64) void shade_general_kernel(const Render
 inline bool is_general(const RenderArgs& a) { return a.depth > 1u || (a.flags & RT_SHADOWS) != 0u; }
 
 constexpr int kPX = 1, kPY = 4, kB = 8;  // geometry chosen by the sweep recorded in profiles/r01_tuning.md
-constexpr int kShadeP = 4;               // records per lane in shade_general_kernel
+constexpr int kShadeP = 2;               // records per lane in shade_general_kernel
 
 }  // namespace
 

@@ -12,43 +12,47 @@ os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
 lines = []
 db = os.path.join(src, "trace", "c3_results.db")
 con = sqlite3.connect(db)
-lines.append("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 50 --warmup 5 --no-cpu-baseline")
+lines.append("# rocprofv3 --kernel-trace --stats (top_kernels view of the rocpd database)")
 lines.append("# kernel, calls, total_us, average_us, percent")
 for name, calls, total, avg, pct in con.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
-    lines.append(f"\"{name}\",{calls},{total:.3f},{avg:.3f},{pct:.3f}")
+    lines.append(f"\"{name[:140]}\",{calls},{total:.3f},{avg:.3f},{pct:.3f}")
 row = con.execute("select grid_size_x, grid_size_y, workgroup_size_x, lds_block_size, vgpr_count, accum_vgpr_count, sgpr_count, scratch_size "
                   "from rocpd_kernel_dispatch d join kernel_symbols k on 1=1 limit 0").fetchall() if False else None
 open(dst + "_kernel_stats.csv", "w").write("\n".join(lines) + "\n")
 
-out = ["# rocprofv3 --pmc passes on bench.py (config C3), averages per dispatch of the render kernel", ""]
-geom = None
-vals = {}
+out = ["# rocprofv3 --pmc passes, averages per dispatch, one block per rtamd kernel", ""]
+per_kernel = {}
 for f in sorted(glob.glob(os.path.join(src, "pmc_*", "c3_results.db"))):
     c = sqlite3.connect(f)
-    q = ("select counter_name, avg(value), count(*), max(grid_size_x), max(grid_size_y), max(workgroup_size_x), max(lds_block_size), max(vgpr_count), "
-         "max(sgpr_count), max(scratch_size) from counters_collection where kernel_name like '%render_kernel%' group by counter_name")
-    for name, v, n, gx, gy, wx, lds, vg, sg, scr in c.execute(q):
-        vals[name] = v
-        geom = (gx, gy, wx, lds, vg, sg, scr)
-        out.append(f"{os.path.basename(os.path.dirname(f)):10s} {name:28s} {v:18.1f}   (n={n})")
-if geom:
-    out.insert(1, f"grid={geom[0]}x{geom[1]} threads, workgroup={geom[2]}, LDS/block={geom[3]} B, VGPRs={geom[4]}, SGPRs={geom[5]}, scratch={geom[6]} B")
-g = vals.get
-if g("SQ_INSTS_VALU"):
-    out += ["", "## derived"]
-    fl = 64 * (2 * g("SQ_INSTS_VALU_FMA_F32", 0) + g("SQ_INSTS_VALU_ADD_F32", 0) + g("SQ_INSTS_VALU_MUL_F32", 0) + g("SQ_INSTS_VALU_TRANS_F32", 0))
-    out.append(f"counter-derived f32 flops per dispatch (64 x (2 FMA + ADD + MUL + TRANS)) = {fl:.4e}")
-    out.append(f"VALU wave-instructions per dispatch = {g('SQ_INSTS_VALU'):.4e}; FMA share = {g('SQ_INSTS_VALU_FMA_F32', 0) / g('SQ_INSTS_VALU'):.3f}")
-    if g("SQ_THREAD_CYCLES_VALU") and g("SQ_ACTIVE_INST_VALU"):
-        out.append(f"VALU lane utilisation (SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)) = {g('SQ_THREAD_CYCLES_VALU') / (64 * g('SQ_ACTIVE_INST_VALU')):.3f}")
-    if g("GRBM_GUI_ACTIVE"):
-        out.append(f"GRBM_GUI_ACTIVE / 8 XCDs = {g('GRBM_GUI_ACTIVE') / 8:.4e} cycles per dispatch")
-    if g("SQ_LDS_IDX_ACTIVE") is not None:
-        out.append(f"LDS bank-conflict cycles / LDS active cycles = {g('SQ_LDS_BANK_CONFLICT', 0):.0f} / {g('SQ_LDS_IDX_ACTIVE'):.4e}")
-    if g("TCC_EA0_WRREQ_sum") is not None:
-        out.append(f"HBM write bytes = TCC_EA0_WRREQ_sum x 64 B = {g('TCC_EA0_WRREQ_sum') * 64:.4e}")
-    if g("TCC_EA0_RDREQ_sum") is not None:
-        out.append(f"HBM read bytes  = TCC_EA0_RDREQ_sum x 64 B x 2 (gfx950 correction, MI355X_MICROARCH.md) = {g('TCC_EA0_RDREQ_sum') * 128:.4e}")
+    q = ("select kernel_name, counter_name, avg(value), count(*), max(grid_size_x), max(grid_size_y), max(workgroup_size_x), max(lds_block_size), max(vgpr_count), "
+         "max(sgpr_count), max(scratch_size) from counters_collection where kernel_name like '%rtamd%' group by kernel_name, counter_name")
+    for kname, name, v, n, gx, gy, wx, lds, vg, sg, scr in c.execute(q):
+        d = per_kernel.setdefault(kname, {"vals": {}, "lines": [], "geom": None})
+        d["vals"][name] = v
+        d["geom"] = (gx, gy, wx, lds, vg, sg, scr)
+        d["lines"].append(f"{os.path.basename(os.path.dirname(f)):10s} {name:28s} {v:18.1f}   (n={n})")
+for kname, d in per_kernel.items():
+    geom, vals = d["geom"], d["vals"]
+    out.append("## " + kname)
+    out.append(f"grid={geom[0]}x{geom[1]} threads, workgroup={geom[2]}, LDS/block={geom[3]} B, VGPRs={geom[4]}, SGPRs={geom[5]}, scratch={geom[6]} B")
+    out += d["lines"]
+    g = vals.get
+    if g("SQ_INSTS_VALU"):
+        out.append("# derived")
+        fl = 64 * (2 * g("SQ_INSTS_VALU_FMA_F32", 0) + g("SQ_INSTS_VALU_ADD_F32", 0) + g("SQ_INSTS_VALU_MUL_F32", 0) + g("SQ_INSTS_VALU_TRANS_F32", 0))
+        out.append(f"counter-derived f32 flops per dispatch (64 x (2 FMA + ADD + MUL + TRANS)) = {fl:.4e}")
+        out.append(f"VALU wave-instructions per dispatch = {g('SQ_INSTS_VALU'):.4e}; FMA share = {g('SQ_INSTS_VALU_FMA_F32', 0) / g('SQ_INSTS_VALU'):.3f}")
+        if g("SQ_THREAD_CYCLES_VALU") and g("SQ_ACTIVE_INST_VALU"):
+            out.append(f"VALU lane utilisation (SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)) = {g('SQ_THREAD_CYCLES_VALU') / (64 * g('SQ_ACTIVE_INST_VALU')):.3f}")
+        if g("GRBM_GUI_ACTIVE"):
+            out.append(f"GRBM_GUI_ACTIVE / 8 XCDs = {g('GRBM_GUI_ACTIVE') / 8:.4e} cycles per dispatch")
+        if g("SQ_LDS_IDX_ACTIVE") is not None:
+            out.append(f"LDS bank-conflict cycles / LDS active cycles = {g('SQ_LDS_BANK_CONFLICT', 0):.0f} / {g('SQ_LDS_IDX_ACTIVE'):.4e}")
+        if g("TCC_EA0_WRREQ_sum") is not None:
+            out.append(f"HBM write bytes = TCC_EA0_WRREQ_sum x 64 B = {g('TCC_EA0_WRREQ_sum') * 64:.4e}")
+        if g("TCC_EA0_RDREQ_sum") is not None:
+            out.append(f"HBM read bytes  = TCC_EA0_RDREQ_sum x 64 B x 2 (gfx950 correction, MI355X_MICROARCH.md) = {g('TCC_EA0_RDREQ_sum') * 128:.4e}")
+    out.append("")
 open(dst + "_pmc.txt", "w").write("\n".join(out) + "\n")
-print("\n".join(lines[:4]))
+print("\n".join(lines[:6]))
 print("\n".join(out))
