@@ -251,3 +251,21 @@ def test_c4_scene_reduced_resolution(gpu_ctx, oracle):
     _assert_same(gpu_ctx.render(m, w, h), ref, "C4 scene")
     parts = [gpu_ctx.render_rows(m, w, h, 0, 135)[0], gpu_ctx.render_rows(m, w, h, 135, 270)[0]]
     _assert_same(np.concatenate(parts), ref, "C4 scene bands")
+
+
+def test_general_path_rgb8_and_hit_idx(gpu_ctx, oracle):
+    """depth 2 + shadows through the two-launch path with RGB8 output and the hit-index plane (both written by the emit kernel + shade kernel)."""
+    w, h = 150, 90
+    objs, lights = scenegen.generate(w, h, 120, 3, seed=44)
+    gpu_ctx.scene_upload(objs, lights)
+    m = _cam(oracle, w, h)
+    gpu, hit = gpu_ctx.render_rows(m, w, h, 10, 77, 2, capi.RT_SHADOWS | capi.RT_OUT_RGB8, want_hit_idx=True)
+    ref, ref_hit = oracle.render(objs, lights, m, w, h, y0=10, y1=77, depth=2, flags=1, channels=3, want_hit_idx=True)
+    assert gpu.shape == (67, w, 3)
+    _assert_same(gpu, ref, "general path RGB8 band")
+    assert np.array_equal(hit, ref_hit)
+    # the record scratch is reused (and regrown) across calls of different sizes
+    big = gpu_ctx.render(m, w, h, 2, capi.RT_SHADOWS)
+    _assert_same(big, oracle.render(objs, lights, m, w, h, depth=2, flags=1), "general path full frame after a band")
+    small = gpu_ctx.render_rows(m, w, h, 0, 5, 2, capi.RT_SHADOWS)[0]
+    _assert_same(small, big[:5], "general path small band after a full frame")
