@@ -627,19 +627,39 @@ constexpr int kShadeP = 2;               // records per lane in shade_general_ke
 
 bool render_needs_records(const RenderArgs& args) { return is_general(args); }
 
+namespace {
+template <int PY, bool EMIT>
+void launch_primary(const RenderArgs& args, hipStream_t stream)
+{
+    const uint32_t rows = args.y1 - args.y0;
+    const dim3 grid((args.w + kWaves * kLX * kPX - 1) / (kWaves * kLX * kPX), (rows + kLY * PY - 1) / (kLY * PY));
+    hipLaunchKernelGGL((render_kernel<kPX, PY, kB, EMIT>), grid, dim3(kWaves * 64), 0, stream, args);
+}
+template <bool EMIT>
+void launch_primary_sized(const RenderArgs& args, hipStream_t stream)
+{
+    // A launch with few tiles (a row band of a multi-GPU split) fills the chip better with 16x8 tiles: measured on 3840-wide bands,
+    // 2 rows of pixels per lane win below ~3000 workgroups of the 4-row geometry (profiles/r01_tuning.md).
+    const uint64_t wgs4 = (uint64_t)((args.w + kWaves * kLX * kPX - 1) / (kWaves * kLX * kPX)) * ((args.y1 - args.y0 + kLY * kPY - 1) / (kLY * kPY));
+    if (wgs4 < 3072)
+        launch_primary<2, EMIT>(args, stream);
+    else
+        launch_primary<kPY, EMIT>(args, stream);
+}
+}  // namespace
+
 hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
 {
     if (args.y1 <= args.y0 || args.w == 0) return hipSuccess;
     const uint32_t rows = args.y1 - args.y0;
-    const dim3 grid((args.w + kWaves * kLX * kPX - 1) / (kWaves * kLX * kPX), (rows + kLY * kPY - 1) / (kLY * kPY));
     if (!is_general(args)) {
-        hipLaunchKernelGGL((render_kernel<kPX, kPY, kB, false>), grid, dim3(kWaves * 64), 0, stream, args);
+        launch_primary_sized<false>(args, stream);
         return hipGetLastError();
     }
     if (!args.rec_count || !args.rec_pix || !args.rec_idx || !args.rec_t) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(args.rec_count, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((render_kernel<kPX, kPY, kB, true>), grid, dim3(kWaves * 64), 0, stream, args);
+    launch_primary_sized<true>(args, stream);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     // sized for the worst case (every pixel hit); workgroups past the record count exit at once, so no host round trip is needed
     const uint64_t npix = (uint64_t)rows * args.w;
