@@ -448,7 +448,7 @@ __global__ __launch_bounds__(kWaves * 64) void render_kernel(const RenderArgs A)
             // renderer.rs:57, object/mod.rs:61-63 — origin + t * direction (origin = 0)
             const float px = 0.0f + best_t[p] * dx[p], py = 0.0f + best_t[p] * dy[p], pz = 0.0f + best_t[p] * dz[p];
             float r = 0.0f, g = 0.0f, b = 0.0f;
-            shade(A, hit, best_i[p], px, py, pz, r, g, b);
+            if (__builtin_amdgcn_ballot_w64(hit) != 0ull) shade(A, hit, best_i[p], px, py, pz, r, g, b);  // most waves see only background
             if (!((inb >> p) & 1u)) continue;
             const uint32_t x = x_base + kLX * (p % PX);
             const uint32_t y = y_base + kLY * (p / PX);
