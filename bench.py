@@ -34,6 +34,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    # Keep stdout for the ONE JSON line: native libraries (RCCL prints a version banner at communicator creation) write to
+    # fd 1 directly, so fd 1 is pointed at stderr for the run and the JSON goes to a saved duplicate of the real stdout.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -51,8 +57,13 @@ def main():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # BENCH_REHEARSE_DIST=1 runs the process-group / RCCL gather code path even with one rank (a 1-GPU box can then exercise it)
+    use_dist = world > 1 or os.environ.get("BENCH_REHEARSE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         dist.init_process_group("nccl", device_id=dev)
 
     w, h, objs, lights = scenegen.config(args.config)
@@ -68,8 +79,8 @@ def main():
     # two band buffers: the gather of frame k (async RCCL collective) overlaps the render of frame k+1
     slots = 2
     band_bufs = [torch.zeros((rows_max, w, 4), dtype=torch.uint8, device=dev) for _ in range(slots)]
-    gather_lists = [[torch.empty_like(band_bufs[0]) for _ in range(world)] if (world > 1 and rank == 0) else None for _ in range(slots)]
-    pipe = bands.GatherPipeline(world, rank, slots=slots)
+    gather_lists = [[torch.empty_like(band_bufs[0]) for _ in range(world)] if (use_dist and rank == 0) else None for _ in range(slots)]
+    pipe = bands.GatherPipeline(world, rank, slots=slots, always_collective=use_dist)
     frame_no = [0]
 
     def step(ev=None):
@@ -86,7 +97,7 @@ def main():
     def fence():
         pipe.drain()
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -104,7 +115,7 @@ def main():
     kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)  # HIP events on the launch stream
 
     tmax = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed_max, kern_ms_max = float(tmax[0]), float(tmax[1])
 
@@ -136,10 +147,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(objs, lights, m, w, h)
-        print(json.dumps(out), flush=True)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

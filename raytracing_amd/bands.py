@@ -59,10 +59,11 @@ class GatherPipeline:
     (RCCL; Work.wait() is a stream-level wait, the host never blocks) and with "gloo" (CPU tests; wait() blocks).
     """
 
-    def __init__(self, world: int, rank: int, slots: int = 2, group=None):
+    def __init__(self, world: int, rank: int, slots: int = 2, group=None, always_collective: bool = False):
         if slots < 1:
             raise ValueError("need at least one slot")
         self.world, self.rank, self.slots, self.group = world, rank, slots, group
+        self.always_collective = always_collective  # issue the (trivial) collective even with one rank: rehearsal of the N > 1 path
         self._work = [None] * slots
 
     def begin(self, k: int) -> int:
@@ -73,7 +74,7 @@ class GatherPipeline:
         return s
 
     def submit(self, k: int, band, gather_list=None):
-        if self.world == 1:
+        if self.world == 1 and not self.always_collective:
             return
         import torch.distributed as dist
         s = k % self.slots

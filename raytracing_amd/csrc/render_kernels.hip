@@ -27,6 +27,10 @@ constexpr int kLX = 16;      // lanes of a wave along x
 constexpr int kLY = 4;       // lanes of a wave along y
 constexpr int kWaves = 4;    // waves per workgroup, side by side along x
 constexpr int kChunk = 1024; // spheres staged in LDS per pass (16 KiB)
+#ifndef RT_SHADOW_CHUNK
+#define RT_SHADOW_CHUNK 2048
+#endif
+constexpr int kShadowChunk = RT_SHADOW_CHUNK;  // spheres per pass in the per-light shadow loops of shade_general_kernel
 
 // math/vec3.rs:118-155 — (xx + yy) + (zz + 0): every product and sum individually rounded
 __device__ __forceinline__ float dot3_ref(float ax, float ay, float az, float bx, float by, float bz)
@@ -235,14 +239,14 @@ __device__ __forceinline__ void trace_general(const RenderArgs& A, float* s_gen,
 // light they share an origin, so the primary-ray 3-FMA filter applies with the per-light constants A.lfilt (scene_prep.cpp:
 // prepare_light_filters); candidates run the reference's exact general-origin test on the ORIGINAL ray (h, u), so the result is
 // bit-identical to the oracle's occluded().  Bit p of `occ` = ray p is blocked.  Contains workgroup barriers.
-template <int P, int B>
+template <int P, int B, int CH>
 __device__ __forceinline__ void trace_shadow(const RenderArgs& A, float* s_buf, int tid, int l, uint32_t need, const float (&hx)[P], const float (&hy)[P],
                                              const float (&hz)[P], const float (&ux)[P], const float (&uy)[P], const float (&uz)[P],
                                              const float (&sd)[P], uint32_t& occ)
 {
     float* const s_x = s_buf;
-    float* const s_y = s_buf + kChunk;
-    float* const s_z = s_buf + 2 * kChunk;
+    float* const s_y = s_buf + CH;
+    float* const s_z = s_buf + 2 * CH;
     float wx[P], wy[P], wz[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -267,8 +271,8 @@ __device__ __forceinline__ void trace_shadow(const RenderArgs& A, float* s_buf, 
     for (int a = A.lalways_off[l]; a < A.lalways_off[l + 1]; ++a) exact(A.lalways[a]);
     uint32_t open = need & ~occ;
     const float4* const filt = A.lfilt + (size_t)l * A.n_pad;
-    for (int c0 = 0; c0 < A.n_pad; c0 += kChunk) {
-        const int cn = min(kChunk, A.n_pad - c0);
+    for (int c0 = 0; c0 < A.n_pad; c0 += CH) {
+        const int cn = min(CH, A.n_pad - c0);
         __syncthreads();
         for (int i = tid; i < cn; i += kWaves * 64) {
             const float4 q = filt[c0 + i];
@@ -495,7 +499,8 @@ __global__ __launch_bounds__(kWaves * 64) void render_kernel(const RenderArgs A)
 template <int P>
 __global__ __launch_bounds__(kWaves * 64) void shade_general_kernel(const RenderArgs A)
 {
-    __shared__ __attribute__((aligned(16))) float s_buf[4 * kChunk];
+    // shared by the bounce filter (4 planes x kChunk) and the per-light shadow filter (3 planes x kShadowChunk)
+    __shared__ __attribute__((aligned(16))) float s_buf[(4 * kChunk > 3 * kShadowChunk) ? 4 * kChunk : 3 * kShadowChunk];
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
     const int lane = tid & 63;
@@ -573,7 +578,7 @@ __global__ __launch_bounds__(kWaves * 64) void shade_general_kernel(const Render
                     sz[p] = vz / sd[p];
                 }
                 uint32_t occ;
-                trace_shadow<P, 8>(A, s_buf, tid, l, alive & some, hx, hy, hz, sx, sy, sz, sd, occ);
+                trace_shadow<P, 8, kShadowChunk>(A, s_buf, tid, l, alive & some, hx, hy, hz, sx, sy, sz, sd, occ);
                 some &= ~occ;
             }
 #pragma unroll
