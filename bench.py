@@ -145,6 +145,7 @@ def main():
                          "kernel_ms": kern_ms, "kernel_ms_max_over_ranks": kern_ms_max,
                          "flops_counted": "%d per (pixel,sphere) filter test x %d tests per launch" % (FLOPS_PER_TEST, my_tests)},
         }
+        out["roofline"]["traffic"], out["roofline"]["traffic_note"] = pmc_traffic(args.config)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(objs, lights, m, w, h)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
@@ -152,6 +153,24 @@ def main():
     ctx.close()
     if use_dist:
         dist.destroy_process_group()
+
+
+def pmc_traffic(config):
+    """HBM bytes per launch of the render kernel from the committed rocprofv3 PMC passes (profiles/r01_c3_pmc.txt: TCC_EA0_WRREQ x 64 B +
+    TCC_EA0_RDREQ x 64 B x 2, the gfx950 correction of MI355X_MICROARCH.md).  Counters cannot be read inside an unprofiled run, so this
+    is the value of the profiled run of the same command; None for other configs or if the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_c3_pmc.txt")
+    if config != "C3" or not os.path.exists(path):
+        return None, "no PMC pass committed for this config"
+    wr = rd = None
+    for line in open(path):
+        if line.startswith("HBM write bytes"):
+            wr = float(line.rsplit("=", 1)[1])
+        elif line.startswith("HBM read bytes"):
+            rd = float(line.rsplit("=", 1)[1])
+    if wr is None or rd is None:
+        return None, "PMC summary has no HBM lines"
+    return wr + rd, "bytes per launch, from profiles/r01_c3_pmc.txt (separate --pmc passes of this command); algorithmic = W*H*4 = 33177600 written"
 
 
 def cpu_baseline(objs, lights, m, w, h):
