@@ -156,14 +156,27 @@ __device__ __forceinline__ float general_filter(int p, const float (&ox)[P], con
     return __builtin_fmaf(a, a, -w);
 }
 
-// P rays per lane against the whole list, sphere data staged per 1024-chunk in LDS (s_gen: cx | cy | cz | -rho).
-// ANY_HIT = false: closest hit (renderer.rs:47-54) -> best_t/best_i.   ANY_HIT = true (RT_SHADOWS extension): bit p of `occ`
-// is set iff some element returns t with RT_SHADOW_EPS < t < tmax[p]; a wave leaves the sphere loop once all its rays are decided.
-// Must be called by every wave of the workgroup (it contains workgroup barriers); `need` selects the live rays of this lane.
-template <int P, bool ANY_HIT>
-__device__ __forceinline__ void trace_general(const RenderArgs& A, float* s_gen, int tid, uint32_t need, const float (&ox)[P], const float (&oy)[P],
-                                              const float (&oz)[P], const float (&ux)[P], const float (&uy)[P], const float (&uz)[P],
-                                              const float (&tmax)[P], uint32_t& occ, float (&best_t)[P], int (&best_i)[P])
+// Workgroup-level helpers of shade_general_kernel.  SPLIT waves of a workgroup hold the SAME 64*P records and each walks every
+// SPLIT-th block of the sphere list; partial results are merged through LDS so that afterwards all of them carry identical
+// values (they then execute the same shading arithmetic redundantly, which keeps every later loop workgroup-uniform).  A wave
+// thus lives 1/SPLIT as long: the launch has SPLIT x more, shorter workgroups, which is what fills 256 CUs when the record list
+// is short (row bands) or the per-record work is long (32 lights x 4096 spheres).
+struct SplitCtx {
+    int wave;       // wave index in the workgroup
+    int part;       // wave % SPLIT: which share of the blocks this wave walks
+    int first;      // index of the first wave of this wave's group (wave - part)
+    int lane;
+    uint32_t* m_occ;  // [kWaves][64]
+    float* m_t;       // [kWaves][P][64]
+    int* m_i;         // [kWaves][P][64]
+};
+
+// P rays per lane against the whole list: closest hit (renderer.rs:47-54) -> best_t/best_i.  Sphere data staged per 1024-chunk
+// in LDS (s_gen: cx | cy | cz | -rho).  Must be called by every wave of the workgroup (barriers); `need` selects the live rays.
+template <int P, int SPLIT>
+__device__ __forceinline__ void trace_general(const RenderArgs& A, float* s_gen, int tid, const SplitCtx& sc, uint32_t need, const float (&ox)[P],
+                                              const float (&oy)[P], const float (&oz)[P], const float (&ux)[P], const float (&uy)[P],
+                                              const float (&uz)[P], float (&best_t)[P], int (&best_i)[P])
 {
     float fx[P], fy[P], fz[P], gx[P], gy[P], gz[P];
 #pragma unroll
@@ -176,13 +189,9 @@ __device__ __forceinline__ void trace_general(const RenderArgs& A, float* s_gen,
         gx[p] = on ? ox[p] : 1.0e18f;
         gy[p] = on ? oy[p] : 1.0e18f;
         gz[p] = on ? oz[p] : 1.0e18f;
-        if (!ANY_HIT) {
-            best_i[p] = -1;
-            best_t[p] = 0.0f;
-        }
+        best_i[p] = -1;
+        best_t[p] = 0.0f;
     }
-    occ = 0u;
-    uint32_t open = need;
     for (int c0 = 0; c0 < A.n_pad; c0 += kChunk) {
         const int cn = min(kChunk, A.n_pad - c0);
         __syncthreads();
@@ -194,8 +203,8 @@ __device__ __forceinline__ void trace_general(const RenderArgs& A, float* s_gen,
             s_gen[3 * kChunk + i] = g.w;
         }
         __syncthreads();
-        if (__builtin_amdgcn_ballot_w64(open != 0u) == 0ull) continue;  // nothing left to decide in this wave (barriers above still run)
-        for (int s0 = 0; s0 < cn; s0 += kGenBlock) {
+        if (__builtin_amdgcn_ballot_w64(need != 0u) == 0ull) continue;  // no live ray in this wave (barriers above still run)
+        for (int s0 = sc.part * kGenBlock; s0 < cn; s0 += kGenBlock * SPLIT) {
             const float4 vx = *reinterpret_cast<const float4*>(&s_gen[s0]);
             const float4 vy = *reinterpret_cast<const float4*>(&s_gen[kChunk + s0]);
             const float4 vz = *reinterpret_cast<const float4*>(&s_gen[2 * kChunk + s0]);
@@ -220,16 +229,26 @@ __device__ __forceinline__ void trace_general(const RenderArgs& A, float* s_gen,
                 for (int p = 0; p < P; ++p) {
                     float t;
                     const bool h = hit_general_exact(ox[p], oy[p], oz[p], ux[p], uy[p], uz[p], s, t) && ((need >> p) & 1u);
-                    if (ANY_HIT) {
-                        if (h && t > RT_SHADOW_EPS && t < tmax[p]) occ |= 1u << p;
-                    } else {
-                        take_closest(h, t, k, best_t[p], best_i[p]);
-                    }
+                    take_closest(h, t, k, best_t[p], best_i[p]);
                 }
             }
-            if (ANY_HIT) {
-                open = need & ~occ;
-                if (__builtin_amdgcn_ballot_w64(open != 0u) == 0ull) break;  // early-out: every shadow ray of this wave is blocked
+        }
+    }
+    if (SPLIT > 1) {  // lexicographic (t, index) minimum over the group: order-independent, so every wave ends with the same result
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            sc.m_t[(sc.wave * P + p) * 64 + sc.lane] = best_t[p];
+            sc.m_i[(sc.wave * P + p) * 64 + sc.lane] = best_i[p];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < SPLIT; ++q) {
+            if (q == sc.part) continue;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const float t = sc.m_t[((sc.first + q) * P + p) * 64 + sc.lane];
+                const int k = sc.m_i[((sc.first + q) * P + p) * 64 + sc.lane];
+                take_closest(k >= 0, t, k, best_t[p], best_i[p]);
             }
         }
     }
@@ -239,8 +258,8 @@ __device__ __forceinline__ void trace_general(const RenderArgs& A, float* s_gen,
 // light they share an origin, so the primary-ray 3-FMA filter applies with the per-light constants A.lfilt (scene_prep.cpp:
 // prepare_light_filters); candidates run the reference's exact general-origin test on the ORIGINAL ray (h, u), so the result is
 // bit-identical to the oracle's occluded().  Bit p of `occ` = ray p is blocked.  Contains workgroup barriers.
-template <int P, int B, int CH>
-__device__ __forceinline__ void trace_shadow(const RenderArgs& A, float* s_buf, int tid, int l, uint32_t need, const float (&hx)[P], const float (&hy)[P],
+template <int P, int B, int CH, int SPLIT>
+__device__ __forceinline__ void trace_shadow(const RenderArgs& A, float* s_buf, int tid, const SplitCtx& sc, int l, uint32_t need, const float (&hx)[P], const float (&hy)[P],
                                              const float (&hz)[P], const float (&ux)[P], const float (&uy)[P], const float (&uz)[P],
                                              const float (&sd)[P], uint32_t& occ)
 {
@@ -268,7 +287,7 @@ __device__ __forceinline__ void trace_shadow(const RenderArgs& A, float* s_buf, 
             }
         }
     };
-    for (int a = A.lalways_off[l]; a < A.lalways_off[l + 1]; ++a) exact(A.lalways[a]);
+    for (int a = A.lalways_off[l] + sc.part; a < A.lalways_off[l + 1]; a += SPLIT) exact(A.lalways[a]);
     uint32_t open = need & ~occ;
     const float4* const filt = A.lfilt + (size_t)l * A.n_pad;
     for (int c0 = 0; c0 < A.n_pad; c0 += CH) {
@@ -282,7 +301,7 @@ __device__ __forceinline__ void trace_shadow(const RenderArgs& A, float* s_buf, 
         }
         __syncthreads();
         if (__builtin_amdgcn_ballot_w64(open != 0u) == 0ull) continue;  // this wave is done (barriers above still run)
-        for (int s0 = 0; s0 < cn; s0 += B) {
+        for (int s0 = sc.part * B; s0 < cn; s0 += B * SPLIT) {
             float m = -1.0f;
             float qx[B], qy[B], qz[B];
 #pragma unroll
@@ -312,6 +331,12 @@ __device__ __forceinline__ void trace_shadow(const RenderArgs& A, float* s_buf, 
             open = need & ~occ;
             if (__builtin_amdgcn_ballot_w64(open != 0u) == 0ull) break;  // early-out: every shadow ray of this wave is blocked
         }
+    }
+    if (SPLIT > 1) {  // OR the group's findings; every wave ends with the same mask
+        sc.m_occ[sc.wave * 64 + sc.lane] = occ;
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < SPLIT; ++q) occ |= sc.m_occ[(sc.first + q) * 64 + sc.lane];
     }
 }
 
@@ -496,18 +521,22 @@ __global__ __launch_bounds__(kWaves * 64) void render_kernel(const RenderArgs A)
 
 // Bounces (renderer.rs:46-73 for i >= 1) and RT_SHADOWS for the hit records emitted by render_kernel<EMIT>.  A wave owns
 // 64*P consecutive records (they come from neighbouring pixels, so the wave votes of trace_general stay effective).
-template <int P>
+template <int P, int SPLIT>
 __global__ __launch_bounds__(kWaves * 64) void shade_general_kernel(const RenderArgs A)
 {
+    __shared__ uint32_t s_occ[kWaves * 64];
+    __shared__ float s_mt[kWaves * P * 64];
+    __shared__ int s_mi[kWaves * P * 64];
     // shared by the bounce filter (4 planes x kChunk) and the per-light shadow filter (3 planes x kShadowChunk)
     __shared__ __attribute__((aligned(16))) float s_buf[(4 * kChunk > 3 * kShadowChunk) ? 4 * kChunk : 3 * kShadowChunk];
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
     const int lane = tid & 63;
     const uint32_t count = *A.rec_count;
-    const uint32_t wg_first = blockIdx.x * (kWaves * 64 * P);
+    const uint32_t wg_first = blockIdx.x * ((kWaves / SPLIT) * 64 * P);
     if (wg_first >= count) return;  // whole workgroup: no barrier has been executed yet
-    const uint32_t wave_first = wg_first + wave * (64 * P);
+    const SplitCtx sc = {wave, wave % SPLIT, wave - wave % SPLIT, lane, s_occ, s_mt, s_mi};
+    const uint32_t wave_first = wg_first + (wave / SPLIT) * (64 * P);  // the SPLIT waves of a group load the same records
 
     const bool shadows = (A.flags & RT_SHADOWS) != 0u;
     float dx[P], dy[P], dz[P], best_t[P], cr[P], cg[P], cb[P], ox[P], oy[P], oz[P], hx[P], hy[P], hz[P];
@@ -531,9 +560,7 @@ __global__ __launch_bounds__(kWaves * 64) void shade_general_kernel(const Render
     // every loop below is uniform over the workgroup: trace_general() contains barriers
     for (uint32_t it = 0; it < A.depth; ++it) {
         if (it > 0) {
-            float no_tmax[P] = {};
-            uint32_t unused;
-            trace_general<P, false>(A, s_buf, tid, alive, ox, oy, oz, dx, dy, dz, no_tmax, unused, best_t, best_i);
+            trace_general<P, SPLIT>(A, s_buf, tid, sc, alive, ox, oy, oz, dx, dy, dz, best_t, best_i);
         }
         float lr[P], lg[P], lb[P];
 #pragma unroll
@@ -578,7 +605,7 @@ __global__ __launch_bounds__(kWaves * 64) void shade_general_kernel(const Render
                     sz[p] = vz / sd[p];
                 }
                 uint32_t occ;
-                trace_shadow<P, 8, kShadowChunk>(A, s_buf, tid, l, alive & some, hx, hy, hz, sx, sy, sz, sd, occ);
+                trace_shadow<P, 8, kShadowChunk, SPLIT>(A, s_buf, tid, sc, l, alive & some, hx, hy, hz, sx, sy, sz, sd, occ);
                 some &= ~occ;
             }
 #pragma unroll
@@ -618,6 +645,7 @@ __global__ __launch_bounds__(kWaves * 64) void shade_general_kernel(const Render
             }
         }
     }
+    if (sc.part != 0) return;  // the group's waves hold identical colours; one of them stores
 #pragma unroll
     for (int p = 0; p < P; ++p)
         if ((valid >> p) & 1u) store_pixel(A, pix[p], cr[p], cg[p], cb[p]);
@@ -668,8 +696,16 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
     if ((e = hipGetLastError()) != hipSuccess) return e;
     // sized for the worst case (every pixel hit); workgroups past the record count exit at once, so no host round trip is needed
     const uint64_t npix = (uint64_t)rows * args.w;
-    const uint32_t per_wg = kWaves * 64 * kShadeP;
-    hipLaunchKernelGGL((shade_general_kernel<kShadeP>), dim3((uint32_t)((npix + per_wg - 1) / per_wg)), dim3(kWaves * 64), 0, stream, args);
+    // Few records (a row band of a multi-GPU split): 4 waves share each record group so that there are 4x more, 4x shorter
+    // workgroups (C5 band of 270 rows: 9.6 -> 8.3 ms); a full frame has enough workgroups and is faster without the redundancy
+    // (C5 full frame 19.0 vs 20.9 ms).  The record count itself lives on the device, so the choice goes by the band's pixel count.
+    if (npix < 2500000ull) {
+        const uint32_t per_wg = (kWaves / 4) * 64 * kShadeP;
+        hipLaunchKernelGGL((shade_general_kernel<kShadeP, 4>), dim3((uint32_t)((npix + per_wg - 1) / per_wg)), dim3(kWaves * 64), 0, stream, args);
+    } else {
+        const uint32_t per_wg = kWaves * 64 * kShadeP;
+        hipLaunchKernelGGL((shade_general_kernel<kShadeP, 1>), dim3((uint32_t)((npix + per_wg - 1) / per_wg)), dim3(kWaves * 64), 0, stream, args);
+    }
     return hipGetLastError();
 }
 
