@@ -269,3 +269,13 @@ def test_general_path_rgb8_and_hit_idx(gpu_ctx, oracle):
     _assert_same(big, oracle.render(objs, lights, m, w, h, depth=2, flags=1), "general path full frame after a band")
     small = gpu_ctx.render_rows(m, w, h, 0, 5, 2, capi.RT_SHADOWS)[0]
     _assert_same(small, big[:5], "general path small band after a full frame")
+
+
+def test_c3_full_size_general_path(gpu_ctx, oracle):
+    """Full 4K frame through the two-launch path (the large-launch geometry of shade_general_kernel): depth 2 with shadows, every 60th row."""
+    w, h, objs, lights = scenegen.config("C3")
+    gpu_ctx.scene_upload(objs, lights)
+    m = _cam(oracle, w, h)
+    gpu = gpu_ctx.render(m, w, h, 2, capi.RT_SHADOWS)
+    ref = oracle.render(objs, lights, m, w, h, row_step=60, depth=2, flags=1)
+    _assert_same(gpu[::60], ref[::60], "C3 full frame, depth 2 + shadows")
