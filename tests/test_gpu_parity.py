@@ -279,3 +279,39 @@ def test_c3_full_size_general_path(gpu_ctx, oracle):
     gpu = gpu_ctx.render(m, w, h, 2, capi.RT_SHADOWS)
     ref = oracle.render(objs, lights, m, w, h, row_step=60, depth=2, flags=1)
     _assert_same(gpu[::60], ref[::60], "C3 full frame, depth 2 + shadows")
+
+
+def test_fuzz_scenes_cameras_modes(gpu_ctx, oracle):
+    """60 random scenes: random sphere clouds (some around / behind the camera), mixed point/ambient lights (some inside spheres),
+    non-default and non-perspective camera matrices (rotation, shear, row 2 not constant), depth 1-3, shadows on/off, RGB8/RGBA8."""
+    rng = np.random.default_rng(2024)
+    f = np.float32
+    for case in range(60):
+        w, h = int(rng.integers(1, 140)), int(rng.integers(1, 90))
+        n, nl = int(rng.integers(0, 180)), int(rng.integers(0, 6))
+        spread = f(rng.choice([3.0, 10.0, 40.0]))
+        cx = (rng.standard_normal(n) * spread).astype(f)
+        cy = (rng.standard_normal(n) * spread).astype(f)
+        cz = (rng.standard_normal(n) * spread - (0 if case % 5 == 0 else spread)).astype(f)
+        rad = (rng.random(n) ** 2 * spread * 0.4 + 1e-3).astype(f)
+        refl = rng.random((3, n)).astype(f) * f(1.5)
+        objs = capi.FlatObjects(cx, cy, cz, rad, refl[0], refl[1], refl[2])
+        kind = (rng.random(nl) < 0.25).astype(np.uint8)
+        lp = (rng.standard_normal((3, nl)) * spread).astype(f)
+        if nl and n and case % 3 == 0:  # put the first light at a sphere centre
+            lp[0][0], lp[1][0], lp[2][0] = cx[0], cy[0], cz[0]
+        lc = rng.random((3, nl)).astype(f)
+        inten = (rng.random(nl) * spread * spread).astype(f)
+        lights = capi.FlatLights(lp[0], lp[1], lp[2], lc[0], lc[1], lc[2], inten, kind=kind)
+        if case % 2 == 0:
+            m = oracle.camera_transform(f(rng.uniform(0.3, 2.5)), f(rng.uniform(0.01, 1.0)), f(rng.uniform(5.0, 2000.0)), f(w) / f(h))
+        else:
+            m = (rng.standard_normal(16) * 0.7).astype(f)
+            m[10] -= f(1.5)  # keep most rays pointing down -z
+        depth = int(rng.integers(1, 4))
+        flags = (capi.RT_SHADOWS if rng.random() < 0.5 else 0) | (capi.RT_OUT_RGB8 if rng.random() < 0.3 else 0)
+        gpu_ctx.scene_upload(objs, lights)
+        gpu, hit = gpu_ctx.render_rows(m, w, h, 0, h, depth, flags, want_hit_idx=True)
+        ref, ref_hit = oracle.render(objs, lights, m, w, h, depth=depth, flags=flags & 1, channels=3 if flags & 2 else 4, want_hit_idx=True)
+        _assert_same(gpu, ref, f"fuzz case {case}: {w}x{h} n={n} l={nl} depth={depth} flags={flags}")
+        assert np.array_equal(hit, ref_hit), f"fuzz case {case}: hit index plane"
