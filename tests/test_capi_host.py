@@ -117,3 +117,15 @@ def test_scenegen_is_deterministic_and_pinned():
 
 
 PINNED_C3_CRC = 0x2DD6F2E
+
+
+def test_missing_library_fails_loudly():
+    """No silent fallback: if librt_mi355x.so cannot be found, loading raises instead of degrading to some CPU path."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from raytracing_amd import capi\n"
+            "try:\n    capi.load()\nexcept FileNotFoundError as e:\n    print('RAISED', 'no CPU fallback' in str(e))\n" % ROOT)
+    env = dict(os.environ, RT_MI355X_LIB="/nonexistent/librt_mi355x.so")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert "RAISED True" in out.stdout, out.stdout + out.stderr
