@@ -31,6 +31,13 @@ struct RenderArgs {
     uint32_t* rec_pix;
     int32_t* rec_idx;
     float* rec_t;
+    // tile queue of the persistent primary kernel: tile_ctr[0] = next tile, tile_ctr[1] = workgroups that have left (library-owned,
+    // zero between launches); the rest is filled in by launch_render
+    uint32_t* tile_ctr;
+    uint32_t strips;                  // 64-pixel column strips per tile row
+    uint32_t tiles4, tiles2, tiles1;  // number of 16-, 8- and 4-row tiles, in queue order
+    uint32_t rows4, rows2;            // rows covered by the first two sections
+    uint32_t tune4, tune2;            // DEV: permille of the band's rows given to the 16- and 8-row sections
 };
 
 // Enqueue the render of args.[y0,y1) on `stream`. Returns the HIP status of the launch.

@@ -366,23 +366,17 @@ __device__ __forceinline__ void store_pixel(const RenderArgs& A, size_t pix, flo
     }
 }
 
-// Primary rays: closest hit over the whole list.  EMIT = false: shade (depth 1, no shadows) and store the pixel — the whole
-// reference path in one launch.  EMIT = true: store black, and append every hit as a record (pixel, element, t) to a dense
-// list for shade_general_kernel (bounces / shadow rays then run with full lanes instead of the frame's ~20 % coverage).
-template <int PX, int PY, int B, bool EMIT>
-__global__ __launch_bounds__(kWaves * 64) void render_kernel(const RenderArgs A)
+// Primary rays of ONE tile (a workgroup's 4 waves side by side: 64 x (4*PY) pixels, PY pixels per lane in one column): closest
+// hit over the whole list.  EMIT = false: shade (depth 1, no shadows) and store the pixel — the whole reference path.
+// EMIT = true: store black, and append every hit as a record (pixel, element, t) to a dense list for shade_general_kernel
+// (bounces / shadow rays then run with full lanes instead of the frame's ~20 % coverage).
+// `staged`: the whole list (one chunk) already sits in LDS; otherwise the list is re-staged chunk by chunk (workgroup barriers).
+template <int PY, int B, bool EMIT>
+__device__ __forceinline__ void render_tile(const RenderArgs& A, float* s_x, float* s_y, float* s_z, bool staged, uint32_t x_base, uint32_t y_base)
 {
-    constexpr int P = PX * PY;
-    // filter constants of the current chunk, SoA so that four spheres' x (y, z) come back in one broadcast ds_read_b128
-    __shared__ __attribute__((aligned(16))) float s_x[kChunk], s_y[kChunk], s_z[kChunk];
-
+    constexpr int P = PY;
     const int tid = threadIdx.x;
-    const int wave = tid >> 6;
     const int lane = tid & 63;
-    const int lx = lane & (kLX - 1);
-    const int ly = lane >> 4;
-    const uint32_t x_base = (blockIdx.x * kWaves + wave) * (kLX * PX) + lx;
-    const uint32_t y_base = A.y0 + blockIdx.y * (kLY * PY) + ly;
 
     float dx[P], dy[P], dz[P], best_t[P];
     int best_i[P];
@@ -391,8 +385,8 @@ __global__ __launch_bounds__(kWaves * 64) void render_kernel(const RenderArgs A)
     // ---- primary rays ----
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        uint32_t x = x_base + kLX * (p % PX);
-        uint32_t y = y_base + kLY * (p / PX);
+        uint32_t x = x_base;
+        uint32_t y = y_base + kLY * p;
         if (x < A.w && y < A.y1) inb |= 1u << p;
         x = min(x, A.w - 1u);
         y = min(y, A.y1 - 1u);
@@ -416,14 +410,16 @@ __global__ __launch_bounds__(kWaves * 64) void render_kernel(const RenderArgs A)
     // ---- hot loop: conservative 3-FMA filter over the whole list, exact test only for candidate blocks ----
     for (int c0 = 0; c0 < A.n_pad; c0 += kChunk) {
         const int cn = min(kChunk, A.n_pad - c0);
-        __syncthreads();  // every wave is done reading the previous chunk
-        for (int i = tid; i < cn; i += kWaves * 64) {
-            const float4 q = A.filt[c0 + i];
-            s_x[i] = q.x;
-            s_y[i] = q.y;
-            s_z[i] = q.z;
+        if (!staged) {
+            __syncthreads();  // every wave is done reading the previous chunk
+            for (int i = tid; i < cn; i += kWaves * 64) {
+                const float4 q = A.filt[c0 + i];
+                s_x[i] = q.x;
+                s_y[i] = q.y;
+                s_z[i] = q.z;
+            }
+            __syncthreads();
         }
-        __syncthreads();
         for (int s0 = 0; s0 < cn; s0 += B) {
             float m = -1.0f;
             float qx[B], qy[B], qz[B];
@@ -479,9 +475,8 @@ __global__ __launch_bounds__(kWaves * 64) void render_kernel(const RenderArgs A)
             float r = 0.0f, g = 0.0f, b = 0.0f;
             if (__builtin_amdgcn_ballot_w64(hit) != 0ull) shade(A, hit, best_i[p], px, py, pz, r, g, b);  // most waves see only background
             if (!((inb >> p) & 1u)) continue;
-            const uint32_t x = x_base + kLX * (p % PX);
-            const uint32_t y = y_base + kLY * (p / PX);
-            const size_t pix = (size_t)(y - A.y0) * A.w + x;
+            const uint32_t y = y_base + kLY * p;
+            const size_t pix = (size_t)(y - A.y0) * A.w + x_base;
             store_pixel(A, pix, hit ? r : 0.0f, hit ? g : 0.0f, hit ? b : 0.0f);
             if (A.hit_idx) A.hit_idx[pix] = best_i[p];
         }
@@ -501,9 +496,8 @@ __global__ __launch_bounds__(kWaves * 64) void render_kernel(const RenderArgs A)
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             const bool in_frame = (inb >> p) & 1u;
-            const uint32_t x = x_base + kLX * (p % PX);
-            const uint32_t y = y_base + kLY * (p / PX);
-            const size_t pix = (size_t)(y - A.y0) * A.w + x;
+            const uint32_t y = y_base + kLY * p;
+            const size_t pix = (size_t)(y - A.y0) * A.w + x_base;
             if (in_frame) {
                 store_pixel(A, pix, 0.0f, 0.0f, 0.0f);
                 if (A.hit_idx) A.hit_idx[pix] = best_i[p];
@@ -515,6 +509,60 @@ __global__ __launch_bounds__(kWaves * 64) void render_kernel(const RenderArgs A)
                 }
             }
             off += (uint32_t)__builtin_popcountll(hitmask[p]);
+        }
+    }
+}
+
+// The primary-ray kernel: a PERSISTENT grid (one workgroup per resident slot of the chip, launch_render) whose workgroups pull
+// tiles from a queue (A.tile_ctr[0], one atomic per tile).  The band is cut into three sections of decreasing tile height —
+// 16-row tiles (4 pixels per lane, the efficient shape) first, then 8-row, then 4-row tiles — so the work units shrink towards
+// the end of the launch and every CU runs dry at nearly the same time; a static grid of equal tiles instead leaves half the chip
+// idle during its last partial round (profiles/r01_tuning.md).  The last workgroup to leave re-arms the queue for the next
+// launch that uses this counter slot (no host memset; also safe to replay).
+template <int B, bool EMIT>
+__global__ __launch_bounds__(kWaves * 64) void render_kernel(const RenderArgs A)
+{
+    // filter constants of the current chunk, SoA so that four spheres' x (y, z) come back in one broadcast ds_read_b128
+    __shared__ __attribute__((aligned(16))) float s_x[kChunk], s_y[kChunk], s_z[kChunk];
+    __shared__ uint32_t s_tile;
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const uint32_t lx = (uint32_t)(wave * kLX + (lane & (kLX - 1)));  // column inside the 64-pixel strip
+    const uint32_t ly = (uint32_t)(lane >> 4);
+
+    const bool staged = A.n_pad <= kChunk;  // the whole list fits one chunk: stage it once per workgroup, not once per tile
+    if (staged) {
+        for (int i = tid; i < A.n_pad; i += kWaves * 64) {
+            const float4 q = A.filt[i];
+            s_x[i] = q.x;
+            s_y[i] = q.y;
+            s_z[i] = q.z;
+        }
+    }
+    const uint32_t n_tiles = A.tiles4 + A.tiles2 + A.tiles1;
+    for (;;) {
+        __syncthreads();  // s_tile of the previous round has been read by everyone (first round: the staged list is visible)
+        if (tid == 0) s_tile = atomicAdd(A.tile_ctr, 1u);
+        __syncthreads();
+        uint32_t t = s_tile;
+        if (t >= n_tiles) break;
+        if (t < A.tiles4) {
+            render_tile<4, B, EMIT>(A, s_x, s_y, s_z, staged, (t % A.strips) * (kWaves * kLX) + lx, A.y0 + (t / A.strips) * (4 * kLY) + ly);
+        } else if ((t -= A.tiles4) < A.tiles2) {
+            render_tile<2, B, EMIT>(A, s_x, s_y, s_z, staged, (t % A.strips) * (kWaves * kLX) + lx, A.y0 + A.rows4 + (t / A.strips) * (2 * kLY) + ly);
+        } else {
+            t -= A.tiles2;
+            render_tile<1, B, EMIT>(A, s_x, s_y, s_z, staged, (t % A.strips) * (kWaves * kLX) + lx, A.y0 + A.rows4 + A.rows2 + (t / A.strips) * kLY + ly);
+        }
+    }
+    // every workgroup does exactly one failing fetch and then reports here, so the last one to arrive knows that nobody will
+    // touch the queue again and resets it; the end of the kernel publishes the two stores to the next launch
+    if (tid == 0) {
+        if (atomicAdd(A.tile_ctr + 1, 1u) == gridDim.x - 1u) {
+            atomicExch(A.tile_ctr, 0u);
+            atomicExch(A.tile_ctr + 1, 0u);
         }
     }
 }
@@ -653,31 +701,67 @@ __global__ __launch_bounds__(kWaves * 64) void shade_general_kernel(const Render
 
 inline bool is_general(const RenderArgs& a) { return a.depth > 1u || (a.flags & RT_SHADOWS) != 0u; }
 
-constexpr int kPX = 1, kPY = 4, kB = 8;  // geometry chosen by the sweep recorded in profiles/r01_tuning.md
-constexpr int kShadeP = 2;               // records per lane in shade_general_kernel
+constexpr int kB = 8;       // spheres per wave vote in the primary loop (sweep in profiles/r01_tuning.md)
+constexpr int kShadeP = 2;  // records per lane in shade_general_kernel
 
 }  // namespace
 
 bool render_needs_records(const RenderArgs& args) { return is_general(args); }
 
 namespace {
-template <int PY, bool EMIT>
-void launch_primary(const RenderArgs& args, hipStream_t stream)
-{
-    const uint32_t rows = args.y1 - args.y0;
-    const dim3 grid((args.w + kWaves * kLX * kPX - 1) / (kWaves * kLX * kPX), (rows + kLY * PY - 1) / (kLY * PY));
-    hipLaunchKernelGGL((render_kernel<kPX, PY, kB, EMIT>), grid, dim3(kWaves * 64), 0, stream, args);
-}
+
+// Resident workgroup slots of the current device for render_kernel<EMIT> (CUs x workgroups per CU), cached per device.
 template <bool EMIT>
-void launch_primary_sized(const RenderArgs& args, hipStream_t stream)
+hipError_t resident_slots(uint32_t& slots)
 {
-    // A launch with few tiles (a row band of a multi-GPU split) fills the chip better with 16x8 tiles: measured on 3840-wide bands,
-    // 2 rows of pixels per lane win below ~3000 workgroups of the 4-row geometry (profiles/r01_tuning.md).
-    const uint64_t wgs4 = (uint64_t)((args.w + kWaves * kLX * kPX - 1) / (kWaves * kLX * kPX)) * ((args.y1 - args.y0 + kLY * kPY - 1) / (kLY * kPY));
-    if (wgs4 < 3072)
-        launch_primary<2, EMIT>(args, stream);
-    else
-        launch_primary<kPY, EMIT>(args, stream);
+    static uint32_t cache[64] = {};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    if (cache[dev] == 0) {
+        int cus = 0, per_cu = 0;
+        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<kB, EMIT>, kWaves * 64, 0)) != hipSuccess) return e;
+        if (cus <= 0 || per_cu <= 0) return hipErrorInvalidValue;
+        cache[dev] = (uint32_t)cus * (uint32_t)per_cu;
+    }
+    slots = cache[dev];
+    return hipSuccess;
+}
+
+// Cut the band into the three tile sections of render_kernel and launch the persistent grid.
+template <bool EMIT>
+hipError_t launch_primary(RenderArgs a, hipStream_t stream)
+{
+    if (!a.tile_ctr) return hipErrorInvalidValue;
+    uint32_t slots = 0;
+    hipError_t e = resident_slots<EMIT>(slots);
+    if (e != hipSuccess) return e;
+    const uint32_t rows = a.y1 - a.y0;
+    a.strips = (a.w + kWaves * kLX - 1) / (kWaves * kLX);
+    const uint64_t tiles16 = (uint64_t)a.strips * ((rows + 15) / 16);
+    uint32_t rows4, rows2;
+    if (tiles16 < 2ull * slots) {
+        // a launch with few tiles (a row band of a multi-GPU split): 8-row tiles fill the chip better (profiles/r01_tuning.md)
+        rows4 = 0;
+        rows2 = (rows + 7) / 8 * 8;
+    } else {
+        // 16-row tiles for most of the band, the last rounds in 8- and 4-row tiles (fractions chosen by sweep)
+        rows4 = (uint32_t)((uint64_t)rows * a.tune4 / 1000) / 16 * 16;
+        rows2 = (uint32_t)((uint64_t)rows * a.tune2 / 1000) / 8 * 8;
+        if (rows4 + rows2 > rows) rows2 = (rows - rows4) / 8 * 8;
+    }
+    const uint32_t rest = rows > rows4 + rows2 ? rows - rows4 - rows2 : 0;
+    a.rows4 = rows4;
+    a.rows2 = rows2;
+    a.tiles4 = a.strips * (rows4 / 16);
+    a.tiles2 = a.strips * (rows2 / 8);
+    a.tiles1 = a.strips * ((rest + 3) / 4);
+    const uint32_t n_tiles = a.tiles4 + a.tiles2 + a.tiles1;
+    const uint32_t grid = n_tiles < slots ? n_tiles : slots;
+    hipLaunchKernelGGL((render_kernel<kB, EMIT>), dim3(grid), dim3(kWaves * 64), 0, stream, a);
+    return hipGetLastError();
 }
 }  // namespace
 
@@ -686,14 +770,12 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
     if (args.y1 <= args.y0 || args.w == 0) return hipSuccess;
     const uint32_t rows = args.y1 - args.y0;
     if (!is_general(args)) {
-        launch_primary_sized<false>(args, stream);
-        return hipGetLastError();
+        return launch_primary<false>(args, stream);
     }
     if (!args.rec_count || !args.rec_pix || !args.rec_idx || !args.rec_t) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(args.rec_count, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
-    launch_primary_sized<true>(args, stream);
-    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if ((e = launch_primary<true>(args, stream)) != hipSuccess) return e;
     // sized for the worst case (every pixel hit); workgroups past the record count exit at once, so no host round trip is needed
     const uint64_t npix = (uint64_t)rows * args.w;
     // Few records (a row band of a multi-GPU split): 4 waves share each record group so that there are 4x more, 4x shorter

@@ -3,6 +3,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -37,7 +38,12 @@ struct rt_ctx {
     // dense hit records for the general path: [count (16 B) | pix | idx | t], capacity in pixels
     void* d_rec = nullptr;
     size_t rec_capacity = 0;
+    // tile-queue counters of the persistent primary kernel: a ring of slots (64 B apart), one per launch in flight
+    uint32_t* d_tile_ctr = nullptr;
+    uint32_t tile_slot = 0;
 };
+
+static constexpr uint32_t kTileSlots = 16;  // launches of one context that may overlap on different streams
 
 static thread_local std::string g_create_err;
 
@@ -110,7 +116,9 @@ int32_t rt_ctx_create(rt_ctx** out, int32_t device_id)
     if (!c) return fail(nullptr, RT_ERR_HIP, "out of host memory");
     c->device = device_id;
     if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess) {
+        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
+        (e = hipMalloc(reinterpret_cast<void**>(&c->d_tile_ctr), kTileSlots * 64)) != hipSuccess ||
+        (e = hipMemset(c->d_tile_ctr, 0, kTileSlots * 64)) != hipSuccess) {
         int32_t rc = fail_hip(nullptr, e, "context setup");
         rt_ctx_destroy(c);
         return rc;
@@ -128,6 +136,7 @@ int32_t rt_ctx_destroy(rt_ctx* c)
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_hit) (void)hipFree(c->d_hit);
     if (c->d_rec) (void)hipFree(c->d_rec);
+    if (c->d_tile_ctr) (void)hipFree(c->d_tile_ctr);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -225,6 +234,13 @@ int32_t rt_render_rows_device(rt_ctx* c, const float m[16], uint32_t w, uint32_t
     a.out = static_cast<uint8_t*>(d_out);
     a.hit_idx = static_cast<int32_t*>(d_hit_idx);
     a.rec_count = nullptr; a.rec_pix = nullptr; a.rec_idx = nullptr; a.rec_t = nullptr;
+    a.tile_ctr = c->d_tile_ctr + (size_t)(c->tile_slot++ % kTileSlots) * 16;
+    a.strips = a.tiles4 = a.tiles2 = a.tiles1 = a.rows4 = a.rows2 = 0;
+    {  // DEV
+        const char* t4 = std::getenv("RT_TUNE4"); const char* t2 = std::getenv("RT_TUNE2");
+        a.tune4 = t4 ? (uint32_t)std::atoi(t4) : 850u;
+        a.tune2 = t2 ? (uint32_t)std::atoi(t2) : 100u;
+    }
     if (render_needs_records(a)) {
         const size_t npix = (size_t)(y1 - y0) * w;
         if (npix > c->rec_capacity) {  // grow the scratch (the previous launches that used it must be finished first)

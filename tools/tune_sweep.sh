@@ -1,10 +1,11 @@
 #!/bin/bash
-# DEV: sweep the RT_TUNE kernel variants on config C3 (run on the GPU box through gpurun).
+# DEV: sweep the tile-section fractions (RT_TUNE4 / RT_TUNE2, permille of rows in 16- and 8-row tiles) on config C3 through gpurun.
 mkdir -p gpurun_out
 : > gpurun_out/tune.txt
-for v in ${VARIANTS:-0 1 2 3 4 5 6 7 8 9}; do
-  echo "== RT_TUNE=$v" >> gpurun_out/tune.txt
-  RT_TUNE=$v timeout -k 10 120 python bench.py --steps 100 --warmup 10 --no-cpu-baseline >> gpurun_out/tune.txt 2>&1 || exit 1
+for v in ${VARIANTS:-"850 100"}; do
+  set -- $v
+  echo "== RT_TUNE4=$1 RT_TUNE2=$2" >> gpurun_out/tune.txt
+  RT_TUNE4=$1 RT_TUNE2=$2 timeout -k 10 120 python bench.py --steps 100 --warmup 10 --no-cpu-baseline >> gpurun_out/tune.txt 2>&1 || exit 1
 done
 python - <<'PY'
 import json
