@@ -37,7 +37,6 @@ struct RenderArgs {
     uint32_t strips;                  // 64-pixel column strips per tile row
     uint32_t tiles4, tiles2, tiles1;  // number of 16-, 8- and 4-row tiles, in queue order
     uint32_t rows4, rows2;            // rows covered by the first two sections
-    uint32_t tune4, tune2;            // DEV: permille of the band's rows given to the 16- and 8-row sections
 };
 
 // Enqueue the render of args.[y0,y1) on `stream`. Returns the HIP status of the launch.

@@ -747,9 +747,9 @@ hipError_t launch_primary(RenderArgs a, hipStream_t stream)
         rows4 = 0;
         rows2 = (rows + 7) / 8 * 8;
     } else {
-        // 16-row tiles for most of the band, the last rounds in 8- and 4-row tiles (fractions chosen by sweep)
-        rows4 = (uint32_t)((uint64_t)rows * a.tune4 / 1000) / 16 * 16;
-        rows2 = (uint32_t)((uint64_t)rows * a.tune2 / 1000) / 8 * 8;
+        // 16-row tiles for 85 % of the band, then 10 % in 8-row and the last 5 % in 4-row tiles (sweep in profiles/r01_tuning.md)
+        rows4 = (uint32_t)((uint64_t)rows * 850 / 1000) / 16 * 16;
+        rows2 = (uint32_t)((uint64_t)rows * 100 / 1000) / 8 * 8;
         if (rows4 + rows2 > rows) rows2 = (rows - rows4) / 8 * 8;
     }
     const uint32_t rest = rows > rows4 + rows2 ? rows - rows4 - rows2 : 0;

@@ -3,7 +3,6 @@
 
 #include <cmath>
 #include <cstdio>
-#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -236,11 +235,6 @@ int32_t rt_render_rows_device(rt_ctx* c, const float m[16], uint32_t w, uint32_t
     a.rec_count = nullptr; a.rec_pix = nullptr; a.rec_idx = nullptr; a.rec_t = nullptr;
     a.tile_ctr = c->d_tile_ctr + (size_t)(c->tile_slot++ % kTileSlots) * 16;
     a.strips = a.tiles4 = a.tiles2 = a.tiles1 = a.rows4 = a.rows2 = 0;
-    {  // DEV
-        const char* t4 = std::getenv("RT_TUNE4"); const char* t2 = std::getenv("RT_TUNE2");
-        a.tune4 = t4 ? (uint32_t)std::atoi(t4) : 850u;
-        a.tune2 = t2 ? (uint32_t)std::atoi(t2) : 100u;
-    }
     if (render_needs_records(a)) {
         const size_t npix = (size_t)(y1 - y0) * w;
         if (npix > c->rec_capacity) {  // grow the scratch (the previous launches that used it must be finished first)
