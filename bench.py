@@ -73,6 +73,12 @@ def main():
 
     y0, y1 = bands.band_rows(h, world, rank)
     rows_max = bands.max_band_rows(h, world)
+    # BENCH_REHEARSE_BAND=G (only with BENCH_REHEARSE_DIST=1, one rank): render just the band one of G ranks would, to measure the
+    # host-side issue rate of render + collective at band size on a 1-GPU box.  The JSON line is then NOT a benchmark result.
+    rehearse_band = int(os.environ.get("BENCH_REHEARSE_BAND", "0")) if (use_dist and world == 1) else 0
+    if rehearse_band > 1:
+        y0, y1 = bands.band_rows(h, rehearse_band, rehearse_band // 2)
+        rows_max = bands.max_band_rows(h, rehearse_band)
     # Non-default streams: their handles are what the C ABI launches on, and the torch events below are recorded on them.
     # One rank, one stream: launches run back to back and the per-launch HIP-event durations are exclusive (clean roofline).
     # Several ranks: every rank renders only a band (270 rows at 8 GPUs), a launch too small to fill the chip on its own, so
@@ -82,7 +88,14 @@ def main():
     streams = [torch.cuda.Stream(dev) for _ in range(slots)]
     torch.cuda.set_stream(streams[0])
     band_bufs = [torch.zeros((rows_max, w, 4), dtype=torch.uint8, device=dev) for _ in range(slots)]
-    gather_lists = [[torch.empty_like(band_bufs[0]) for _ in range(world)] if (use_dist and rank == 0) else None for _ in range(slots)]
+    # rank 0 receives every band straight into its place in a [h, w, 4] frame (one frame per slot): the collective assembles the
+    # image, no copy follows (the configs' heights divide by 1/2/4/8; otherwise separate buffers + bands.assemble)
+    gather_lists = [None] * slots
+    if use_dist and rank == 0:
+        for s_ in range(slots):
+            frame = torch.zeros((h, w, 4), dtype=torch.uint8, device=dev)
+            views = bands.frame_gather_list(frame, h, world) if rows_max * world == h else None  # (a band rehearsal has a short band)
+            gather_lists[s_] = views or [torch.empty_like(band_bufs[0]) for _ in range(world)]
     pipe = bands.GatherPipeline(world, rank, slots=slots, always_collective=use_dist)
     frame_no = [0]
 
@@ -125,7 +138,7 @@ def main():
     elapsed_max, kern_ms_max = float(tmax[0]), float(tmax[1])
 
     if rank == 0:
-        rays_per_step = w * h
+        rays_per_step = w * h if rehearse_band <= 1 else (y1 - y0) * w
         value = rays_per_step * args.steps / elapsed_max
         # roofline of the dominant kernel (this rank's launch): executed flops of the filter loop / its own duration
         my_tests = (y1 - y0) * w * objs.n
@@ -151,6 +164,8 @@ def main():
                          "flops_counted": "%d per (pixel,sphere) filter test x %d tests per launch" % (FLOPS_PER_TEST, my_tests)},
         }
         out["roofline"]["traffic"], out["roofline"]["traffic_note"] = pmc_traffic(args.config)
+        if rehearse_band > 1:
+            out["rehearsal"] = "one rank rendering the band of 1/%d of the frame: host issue-rate probe, not a result" % rehearse_band
         if slots > 1:
             out["roofline"]["kernel_ms_note"] = ("%d frames in flight on %d streams: per-launch durations overlap, so achieved/frac here "
                                                  "understate the steady-state rate; the exclusive figure is the one-rank run" % (slots, slots))

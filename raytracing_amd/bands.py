@@ -21,6 +21,16 @@ def max_band_rows(h: int, world: int) -> int:
     return max(band_rows(h, world, r)[1] - band_rows(h, world, r)[0] for r in range(world))
 
 
+def frame_gather_list(frame, h: int, world: int):
+    """Rank 0: the gather's receive list as row views INTO `frame` ([h, w, ch], contiguous), so the collective itself
+    assembles the frame and no copy follows.  Possible when every band has the same height (h % world == 0: the views are
+    disjoint and each is contiguous); returns None otherwise (use separate buffers + assemble())."""
+    if h % world != 0 or frame.shape[0] != h or not frame.is_contiguous():
+        return None
+    rows = h // world
+    return [frame[r * rows:(r + 1) * rows] for r in range(world)]
+
+
 def gather_bands(local_band, h: int, world: int, rank: int, group=None, gather_list=None):
     """Gather per-rank bands (torch uint8 tensors [rows_r, w, ch], padded to the largest band) to rank 0.
 
@@ -37,6 +47,10 @@ def gather_bands(local_band, h: int, world: int, rank: int, group=None, gather_l
     if world == 1:
         return local_band[:h]
     if rank == 0:
+        if gather_list is None and h % world == 0:  # equal bands: receive straight into the frame
+            frame = torch.empty((h,) + tuple(local_band.shape[1:]), dtype=local_band.dtype, device=local_band.device)
+            dist.gather(local_band, gather_list=frame_gather_list(frame, h, world), dst=0, group=group)
+            return frame
         if gather_list is None:
             gather_list = [torch.empty_like(local_band) for _ in range(world)]
         dist.gather(local_band, gather_list=gather_list, dst=0, group=group)

@@ -28,6 +28,15 @@ def test_band_rows_partition():
         bands.band_rows(10, 2, 2)
 
 
+def test_frame_gather_list_views():
+    frame = torch.zeros((8, 3, 4), dtype=torch.uint8)
+    views = bands.frame_gather_list(frame, 8, 4)
+    assert len(views) == 4 and all(v.is_contiguous() and v.shape == (2, 3, 4) for v in views)
+    views[2].fill_(7)
+    assert frame[4:6].eq(7).all() and frame[:4].eq(0).all() and frame[6:].eq(0).all()
+    assert bands.frame_gather_list(frame, 8, 3) is None  # unequal bands: no zero-copy layout
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
