@@ -30,6 +30,10 @@ constexpr int kChunk = 1024; // spheres staged in LDS per pass (16 KiB)
 #ifndef RT_SHADOW_CHUNK
 #define RT_SHADOW_CHUNK 2048
 #endif
+#ifndef RT_SHADOW_B
+#define RT_SHADOW_B 8
+#endif
+constexpr int kShadowB = RT_SHADOW_B;  // spheres per wave vote in the shadow loops
 constexpr int kShadowChunk = RT_SHADOW_CHUNK;  // spheres per pass in the per-light shadow loops of shade_general_kernel
 
 // math/vec3.rs:118-155 — (xx + yy) + (zz + 0): every product and sum individually rounded
@@ -653,7 +657,7 @@ __global__ __launch_bounds__(kWaves * 64) void shade_general_kernel(const Render
                     sz[p] = vz / sd[p];
                 }
                 uint32_t occ;
-                trace_shadow<P, 8, kShadowChunk, SPLIT>(A, s_buf, tid, sc, l, alive & some, hx, hy, hz, sx, sy, sz, sd, occ);
+                trace_shadow<P, kShadowB, kShadowChunk, SPLIT>(A, s_buf, tid, sc, l, alive & some, hx, hy, hz, sx, sy, sz, sd, occ);
                 some &= ~occ;
             }
 #pragma unroll
