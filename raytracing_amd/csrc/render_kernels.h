@@ -31,6 +31,10 @@ struct RenderArgs {
     uint32_t* rec_pix;
     int32_t* rec_idx;
     float* rec_t;
+    uint32_t rec_cap;     // capacity (records) of every rec_* plane
+    uint32_t iter;        // iteration of renderer.rs:46 the general-ray kernels work on (set by launch_render)
+    float* rec_state;     // depth > 1: 9 planes of rec_cap floats (origin, direction, colour of the bounce ray); else null
+    uint32_t* rec_occ;    // RT_SHADOWS: ceil(n_lights / 32) planes of rec_cap words, occlusion bit per (record, light); else null
     // tile queue of the persistent primary kernel: tile_ctr[0] = next tile, tile_ctr[1] = workgroups that have left (library-owned,
     // zero between launches); the rest is filled in by launch_render
     uint32_t* tile_ctr;
@@ -44,6 +48,9 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream);
 
 // True if launch_render needs the rec_* scratch buffers for these args (depth > 1 or RT_SHADOWS).
 bool render_needs_records(const RenderArgs& args);
+
+// Which optional scratch planes these args need beside count/pix/idx/t: rec_state (9 float planes) and rec_occ (occ_words planes).
+void render_scratch_layout(const RenderArgs& args, bool& need_state, uint32_t& occ_words);
 
 // Name of the kernel variant launch_render picks for these args (for profiles / bench output).
 const char* render_kernel_name(const RenderArgs& args);

@@ -34,7 +34,7 @@ constexpr int kChunk = 1024; // spheres staged in LDS per pass (16 KiB)
 #define RT_SHADOW_B 8
 #endif
 constexpr int kShadowB = RT_SHADOW_B;  // spheres per wave vote in the shadow loops
-constexpr int kShadowChunk = RT_SHADOW_CHUNK;  // spheres per pass in the per-light shadow loops of shade_general_kernel
+constexpr int kShadowChunk = RT_SHADOW_CHUNK;  // spheres per pass in the per-light shadow loops of shadow_mask_kernel
 
 // math/vec3.rs:118-155 — (xx + yy) + (zz + 0): every product and sum individually rounded
 __device__ __forceinline__ float dot3_ref(float ax, float ay, float az, float bx, float by, float bz)
@@ -160,25 +160,10 @@ __device__ __forceinline__ float general_filter(int p, const float (&ox)[P], con
     return __builtin_fmaf(a, a, -w);
 }
 
-// Workgroup-level helpers of shade_general_kernel.  SPLIT waves of a workgroup hold the SAME 64*P records and each walks every
-// SPLIT-th block of the sphere list; partial results are merged through LDS so that afterwards all of them carry identical
-// values (they then execute the same shading arithmetic redundantly, which keeps every later loop workgroup-uniform).  A wave
-// thus lives 1/SPLIT as long: the launch has SPLIT x more, shorter workgroups, which is what fills 256 CUs when the record list
-// is short (row bands) or the per-record work is long (32 lights x 4096 spheres).
-struct SplitCtx {
-    int wave;       // wave index in the workgroup
-    int part;       // wave % SPLIT: which share of the blocks this wave walks
-    int first;      // index of the first wave of this wave's group (wave - part)
-    int lane;
-    uint32_t* m_occ;  // [kWaves][64]
-    float* m_t;       // [kWaves][P][64]
-    int* m_i;         // [kWaves][P][64]
-};
-
 // P rays per lane against the whole list: closest hit (renderer.rs:47-54) -> best_t/best_i.  Sphere data staged per 1024-chunk
 // in LDS (s_gen: cx | cy | cz | -rho).  Must be called by every wave of the workgroup (barriers); `need` selects the live rays.
-template <int P, int SPLIT>
-__device__ __forceinline__ void trace_general(const RenderArgs& A, float* s_gen, int tid, const SplitCtx& sc, uint32_t need, const float (&ox)[P],
+template <int P>
+__device__ __forceinline__ void trace_general(const RenderArgs& A, float* s_gen, int tid, uint32_t need, const float (&ox)[P],
                                               const float (&oy)[P], const float (&oz)[P], const float (&ux)[P], const float (&uy)[P],
                                               const float (&uz)[P], float (&best_t)[P], int (&best_i)[P])
 {
@@ -208,7 +193,7 @@ __device__ __forceinline__ void trace_general(const RenderArgs& A, float* s_gen,
         }
         __syncthreads();
         if (__builtin_amdgcn_ballot_w64(need != 0u) == 0ull) continue;  // no live ray in this wave (barriers above still run)
-        for (int s0 = sc.part * kGenBlock; s0 < cn; s0 += kGenBlock * SPLIT) {
+        for (int s0 = 0; s0 < cn; s0 += kGenBlock) {
             const float4 vx = *reinterpret_cast<const float4*>(&s_gen[s0]);
             const float4 vy = *reinterpret_cast<const float4*>(&s_gen[kChunk + s0]);
             const float4 vz = *reinterpret_cast<const float4*>(&s_gen[2 * kChunk + s0]);
@@ -238,32 +223,14 @@ __device__ __forceinline__ void trace_general(const RenderArgs& A, float* s_gen,
             }
         }
     }
-    if (SPLIT > 1) {  // lexicographic (t, index) minimum over the group: order-independent, so every wave ends with the same result
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            sc.m_t[(sc.wave * P + p) * 64 + sc.lane] = best_t[p];
-            sc.m_i[(sc.wave * P + p) * 64 + sc.lane] = best_i[p];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < SPLIT; ++q) {
-            if (q == sc.part) continue;
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                const float t = sc.m_t[((sc.first + q) * P + p) * 64 + sc.lane];
-                const int k = sc.m_i[((sc.first + q) * P + p) * 64 + sc.lane];
-                take_closest(k >= 0, t, k, best_t[p], best_i[p]);
-            }
-        }
-    }
 }
 
 // RT_SHADOWS, one point light `l`: P shadow rays per lane (from hit point h toward lp, direction u, length sd).  Seen from the
 // light they share an origin, so the primary-ray 3-FMA filter applies with the per-light constants A.lfilt (scene_prep.cpp:
 // prepare_light_filters); candidates run the reference's exact general-origin test on the ORIGINAL ray (h, u), so the result is
 // bit-identical to the oracle's occluded().  Bit p of `occ` = ray p is blocked.  Contains workgroup barriers.
-template <int P, int B, int CH, int SPLIT>
-__device__ __forceinline__ void trace_shadow(const RenderArgs& A, float* s_buf, int tid, const SplitCtx& sc, int l, uint32_t need, const float (&hx)[P], const float (&hy)[P],
+template <int P, int B, int CH>
+__device__ __forceinline__ void trace_shadow(const RenderArgs& A, float* s_buf, int tid, int l, uint32_t need, const float (&hx)[P], const float (&hy)[P],
                                              const float (&hz)[P], const float (&ux)[P], const float (&uy)[P], const float (&uz)[P],
                                              const float (&sd)[P], uint32_t& occ)
 {
@@ -291,7 +258,7 @@ __device__ __forceinline__ void trace_shadow(const RenderArgs& A, float* s_buf, 
             }
         }
     };
-    for (int a = A.lalways_off[l] + sc.part; a < A.lalways_off[l + 1]; a += SPLIT) exact(A.lalways[a]);
+    for (int a = A.lalways_off[l]; a < A.lalways_off[l + 1]; ++a) exact(A.lalways[a]);
     uint32_t open = need & ~occ;
     const float4* const filt = A.lfilt + (size_t)l * A.n_pad;
     for (int c0 = 0; c0 < A.n_pad; c0 += CH) {
@@ -305,7 +272,7 @@ __device__ __forceinline__ void trace_shadow(const RenderArgs& A, float* s_buf, 
         }
         __syncthreads();
         if (__builtin_amdgcn_ballot_w64(open != 0u) == 0ull) continue;  // this wave is done (barriers above still run)
-        for (int s0 = sc.part * B; s0 < cn; s0 += B * SPLIT) {
+        for (int s0 = 0; s0 < cn; s0 += B) {
             float m = -1.0f;
             float qx[B], qy[B], qz[B];
 #pragma unroll
@@ -335,12 +302,6 @@ __device__ __forceinline__ void trace_shadow(const RenderArgs& A, float* s_buf, 
             open = need & ~occ;
             if (__builtin_amdgcn_ballot_w64(open != 0u) == 0ull) break;  // early-out: every shadow ray of this wave is blocked
         }
-    }
-    if (SPLIT > 1) {  // OR the group's findings; every wave ends with the same mask
-        sc.m_occ[sc.wave * 64 + sc.lane] = occ;
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < SPLIT; ++q) occ |= sc.m_occ[(sc.first + q) * 64 + sc.lane];
     }
 }
 
@@ -372,7 +333,7 @@ __device__ __forceinline__ void store_pixel(const RenderArgs& A, size_t pix, flo
 
 // Primary rays of ONE tile (a workgroup's 4 waves side by side: 64 x (4*PY) pixels, PY pixels per lane in one column): closest
 // hit over the whole list.  EMIT = false: shade (depth 1, no shadows) and store the pixel — the whole reference path.
-// EMIT = true: store black, and append every hit as a record (pixel, element, t) to a dense list for shade_general_kernel
+// EMIT = true: store black, and append every hit as a record (pixel, element, t) to a dense list for the general-ray kernels below
 // (bounces / shadow rays then run with full lanes instead of the frame's ~20 % coverage).
 // `staged`: the whole list (one chunk) already sits in LDS; otherwise the list is re-staged chunk by chunk (workgroup barriers).
 template <int PY, int B, bool EMIT>
@@ -571,142 +532,215 @@ __global__ __launch_bounds__(kWaves * 64) void render_kernel(const RenderArgs A)
     }
 }
 
-// Bounces (renderer.rs:46-73 for i >= 1) and RT_SHADOWS for the hit records emitted by render_kernel<EMIT>.  A wave owns
-// 64*P consecutive records (they come from neighbouring pixels, so the wave votes of trace_general stay effective).
-template <int P, int SPLIT>
-__global__ __launch_bounds__(kWaves * 64) void shade_general_kernel(const RenderArgs A)
+// ---- general rays (depth > 1, RT_SHADOWS): one pass of two kernels per iteration of renderer.rs:46 over the dense hit records ----
+// Ray state of record r at iteration A.iter: iteration 0 = the primary ray (origin 0, direction recomputed from the pixel with
+// the reference's arithmetic); later iterations = the bounce ray that shade_iter_kernel stored (planes of A.rec_state).
+enum { kStOx = 0, kStOy, kStOz, kStDx, kStDy, kStDz, kStCr, kStCg, kStCb, kStPlanes };
+
+__device__ __forceinline__ void load_ray(const RenderArgs& A, uint32_t r, bool ok, uint32_t pix, float& ox, float& oy, float& oz, float& dx, float& dy, float& dz)
 {
-    __shared__ uint32_t s_occ[kWaves * 64];
-    __shared__ float s_mt[kWaves * P * 64];
-    __shared__ int s_mi[kWaves * P * 64];
-    // shared by the bounce filter (4 planes x kChunk) and the per-light shadow filter (3 planes x kShadowChunk)
-    __shared__ __attribute__((aligned(16))) float s_buf[(4 * kChunk > 3 * kShadowChunk) ? 4 * kChunk : 3 * kShadowChunk];
+    if (A.iter == 0u) {
+        const uint32_t y = A.y0 + pix / A.w, x = pix % A.w;
+        primary_dir(A, x, y, dx, dy, dz);
+        ox = oy = oz = 0.0f;
+    } else {
+        const size_t c = A.rec_cap, i = ok ? r : 0u;
+        ox = A.rec_state[kStOx * c + i]; oy = A.rec_state[kStOy * c + i]; oz = A.rec_state[kStOz * c + i];
+        dx = A.rec_state[kStDx * c + i]; dy = A.rec_state[kStDy * c + i]; dz = A.rec_state[kStDz * c + i];
+    }
+}
+
+// RT_SHADOWS (EXTENSION — the reference has no occlusion, light/point.rs:25-30): occlusion bits of every (record, point light)
+// pair of this iteration, semantics of the oracle's occluded().  A persistent grid pulls tiles (light l, group of 4 waves x 64 lanes
+// x P records) from the queue A.tile_ctr, light-major, so that all rays of a tile end at the same light: seen from the light they
+// share an origin and the primary loop's 3-FMA filter applies (trace_shadow) with P = 4 rays per lane — the same loop shape,
+// LDS traffic and issue rate as the primary kernel.  Result: bit (l & 31) of A.rec_occ[(l >> 5) * rec_cap + r] (zeroed by the host).
+template <int P, int B, int CH>
+__global__ __launch_bounds__(kWaves * 64) void shadow_mask_kernel(const RenderArgs A)
+{
+    __shared__ __attribute__((aligned(16))) float s_buf[3 * CH];
+    __shared__ uint32_t s_tile;
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
     const int lane = tid & 63;
     const uint32_t count = *A.rec_count;
-    const uint32_t wg_first = blockIdx.x * ((kWaves / SPLIT) * 64 * P);
-    if (wg_first >= count) return;  // whole workgroup: no barrier has been executed yet
-    const SplitCtx sc = {wave, wave % SPLIT, wave - wave % SPLIT, lane, s_occ, s_mt, s_mi};
-    const uint32_t wave_first = wg_first + (wave / SPLIT) * (64 * P);  // the SPLIT waves of a group load the same records
+    const uint32_t per_group = kWaves * 64 * P;
+    const uint32_t groups = (count + per_group - 1) / per_group;
+    const uint32_t n_tiles = groups * (uint32_t)A.n_lights;
+    for (;;) {
+        __syncthreads();
+        if (tid == 0) s_tile = atomicAdd(A.tile_ctr, 1u);
+        __syncthreads();
+        const uint32_t t = s_tile;
+        if (t >= n_tiles) break;
+        const int l = (int)(t / groups);
+        const float4 lp = A.lpos[l];
+        if (A.lcol[l].w != 0.0f) continue;  // ambient lights are never shadowed (uniform over the workgroup)
+        const uint32_t first = (t % groups) * per_group + (uint32_t)wave * (64 * P);
+        float hx[P], hy[P], hz[P], sx[P], sy[P], sz[P], sd[P];
+        uint32_t need = 0u;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const uint32_t r = first + p * 64 + lane;
+            bool ok = r < count;
+            const int idx = ok ? A.rec_idx[r] : -1;
+            ok = ok && idx >= 0;  // a record whose ray has missed is dead (shade_iter_kernel)
+            const uint32_t pix = ok ? A.rec_pix[r] : 0u;
+            const float tt = ok ? A.rec_t[r] : 0.0f;
+            float ox, oy, oz, dx, dy, dz;
+            load_ray(A, r, ok, pix, ox, oy, oz, dx, dy, dz);
+            hx[p] = ox + tt * dx;  // renderer.rs:57
+            hy[p] = oy + tt * dy;
+            hz[p] = oz + tt * dz;
+            {  // light/point.rs:25-30: a light whose contribution is cut off casts no shadow ray
+                const float vx = hx[p] - lp.x, vy = hy[p] - lp.y, vz = hz[p] - lp.z;
+                const float dist = sqrtf(dot3_ref(vx, vy, vz, vx, vy, vz));
+                const float in = lp.w / (dist * dist);
+                if (ok && !(in <= 1.1920929e-7f)) need |= 1u << p;
+            }
+            const float vx = lp.x - hx[p], vy = lp.y - hy[p], vz = lp.z - hz[p];
+            sd[p] = sqrtf(dot3_ref(vx, vy, vz, vx, vy, vz));
+            sx[p] = vx / sd[p];
+            sy[p] = vy / sd[p];
+            sz[p] = vz / sd[p];
+        }
+        uint32_t occ;
+        trace_shadow<P, B, CH>(A, s_buf, tid, l, need, hx, hy, hz, sx, sy, sz, sd, occ);
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+            if ((occ >> p) & 1u) atomicOr(A.rec_occ + (size_t)(l >> 5) * A.rec_cap + (first + p * 64 + lane), 1u << (l & 31));
+    }
+    if (tid == 0) {  // re-arm the queue (see render_kernel)
+        if (atomicAdd(A.tile_ctr + 1, 1u) == gridDim.x - 1u) {
+            atomicExch(A.tile_ctr, 0u);
+            atomicExch(A.tile_ctr + 1, 0u);
+        }
+    }
+}
 
+// One iteration (A.iter) of renderer.rs:46-73 for the live records: hit point, lights in list order (occlusion bits from
+// shadow_mask_kernel when RT_SHADOWS), (x) reflectiveness; then either the final store (last iteration) or the bounce (normal at
+// the OLD origin, renderer.rs:68; reflect, object/mod.rs:71-73; no epsilon) and the closest hit of the bounce ray (trace_general).
+// A ray that misses keeps its colour for good (renderer.rs:47-56: prev_info stays untouched), so its pixel is stored at once and the
+// record is marked dead (rec_idx = -1).  A wave owns 64*P consecutive records (neighbouring pixels: wave votes stay effective).
+template <int P>
+__global__ __launch_bounds__(kWaves * 64) void shade_iter_kernel(const RenderArgs A)
+{
+    __shared__ __attribute__((aligned(16))) float s_buf[4 * kChunk];
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const uint32_t count = *A.rec_count;
+    const uint32_t wg_first = blockIdx.x * (kWaves * 64 * P);
+    if (wg_first >= count) return;  // whole workgroup: no barrier has been executed yet
+    const uint32_t wave_first = wg_first + wave * (64 * P);
     const bool shadows = (A.flags & RT_SHADOWS) != 0u;
-    float dx[P], dy[P], dz[P], best_t[P], cr[P], cg[P], cb[P], ox[P], oy[P], oz[P], hx[P], hy[P], hz[P];
+    const bool last = A.iter + 1u >= A.depth;  // renderer.rs:67 (i < limit)
+    const size_t cap = A.rec_cap;
+
+    float dx[P], dy[P], dz[P], ox[P], oy[P], oz[P], hx[P], hy[P], hz[P], cr[P], cg[P], cb[P], lr[P], lg[P], lb[P], best_t[P];
     int best_i[P];
-    uint32_t pix[P];
-    uint32_t alive = 0u, valid = 0u;
+    uint32_t pix[P], rec[P];
+    uint32_t alive = 0u;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         const uint32_t r = wave_first + p * 64 + lane;
-        const bool ok = r < count;
-        pix[p] = ok ? A.rec_pix[r] : 0u;
+        rec[p] = r;
+        bool ok = r < count;
         best_i[p] = ok ? A.rec_idx[r] : -1;
+        ok = ok && best_i[p] >= 0;
+        pix[p] = ok ? A.rec_pix[r] : 0u;
         best_t[p] = ok ? A.rec_t[r] : 0.0f;
-        if (ok) valid |= 1u << p;
-        const uint32_t y = A.y0 + pix[p] / A.w, x = pix[p] % A.w;
-        primary_dir(A, x, y, dx[p], dy[p], dz[p]);
-        cr[p] = cg[p] = cb[p] = 0.0f;
-        ox[p] = oy[p] = oz[p] = 0.0f;
+        if (ok) alive |= 1u << p;
+        load_ray(A, r, ok, pix[p], ox[p], oy[p], oz[p], dx[p], dy[p], dz[p]);
+        if (A.iter == 0u) {
+            cr[p] = cg[p] = cb[p] = 0.0f;  // renderer.rs:42
+        } else {
+            const size_t i = ok ? r : 0u;
+            cr[p] = A.rec_state[kStCr * cap + i]; cg[p] = A.rec_state[kStCg * cap + i]; cb[p] = A.rec_state[kStCb * cap + i];
+        }
+        hx[p] = ox[p] + best_t[p] * dx[p];  // renderer.rs:57
+        hy[p] = oy[p] + best_t[p] * dy[p];
+        hz[p] = oz[p] + best_t[p] * dz[p];
+        lr[p] = cr[p];                      // renderer.rs:59
+        lg[p] = cg[p];
+        lb[p] = cb[p];
     }
-    alive = valid;
-    // every loop below is uniform over the workgroup: trace_general() contains barriers
-    for (uint32_t it = 0; it < A.depth; ++it) {
-        if (it > 0) {
-            trace_general<P, SPLIT>(A, s_buf, tid, sc, alive, ox, oy, oz, dx, dy, dz, best_t, best_i);
-        }
-        float lr[P], lg[P], lb[P];
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            if (best_i[p] < 0) alive &= ~(1u << p);  // a miss leaves prev_info untouched: every later iteration misses identically
-            hx[p] = ox[p] + best_t[p] * dx[p];       // renderer.rs:57
-            hy[p] = oy[p] + best_t[p] * dy[p];
-            hz[p] = oz[p] + best_t[p] * dz[p];
-            lr[p] = cr[p];                           // renderer.rs:59
-            lg[p] = cg[p];
-            lb[p] = cb[p];
-        }
-        for (int l = 0; l < A.n_lights; ++l) {  // renderer.rs:60-64, list order
-            const float4 lp = A.lpos[l];
-            const float4 lc = A.lcol[l];
-            if (lc.w != 0.0f) {  // light/ambient.rs:23-25
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    lr[p] = lr[p] + lc.x;
-                    lg[p] = lg[p] + lc.y;
-                    lb[p] = lb[p] + lc.z;
-                }
-                continue;
-            }
-            float in[P];
-            uint32_t some = 0u;
-#pragma unroll
-            for (int p = 0; p < P; ++p) {  // light/point.rs:25-30
-                const float vx = hx[p] - lp.x, vy = hy[p] - lp.y, vz = hz[p] - lp.z;
-                const float dist = sqrtf(dot3_ref(vx, vy, vz, vx, vy, vz));
-                in[p] = lp.w / (dist * dist);
-                if (!(in[p] <= 1.1920929e-7f)) some |= 1u << p;
-            }
-            if (shadows) {  // EXTENSION: occlusion toward the light, semantics of the oracle's occluded()
-                float sx[P], sy[P], sz[P], sd[P];
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    const float vx = lp.x - hx[p], vy = lp.y - hy[p], vz = lp.z - hz[p];
-                    sd[p] = sqrtf(dot3_ref(vx, vy, vz, vx, vy, vz));
-                    sx[p] = vx / sd[p];
-                    sy[p] = vy / sd[p];
-                    sz[p] = vz / sd[p];
-                }
-                uint32_t occ;
-                trace_shadow<P, kShadowB, kShadowChunk, SPLIT>(A, s_buf, tid, sc, l, alive & some, hx, hy, hz, sx, sy, sz, sd, occ);
-                some &= ~occ;
-            }
+    for (int l = 0; l < A.n_lights; ++l) {  // renderer.rs:60-64, list order
+        const float4 lp = A.lpos[l];
+        const float4 lc = A.lcol[l];
+        if (lc.w != 0.0f) {  // light/ambient.rs:23-25
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                if ((some >> p) & 1u) {
-                    lr[p] = lr[p] + in[p] * lc.x;
-                    lg[p] = lg[p] + in[p] * lc.y;
-                    lb[p] = lb[p] + in[p] * lc.z;
-                }
+                lr[p] = lr[p] + lc.x;
+                lg[p] = lg[p] + lc.y;
+                lb[p] = lb[p] + lc.z;
             }
+            continue;
         }
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-            const bool on = (alive >> p) & 1u;
-            const float4 rf = A.refl[on ? best_i[p] : 0];
-            if (on) {  // renderer.rs:66
-                cr[p] = lr[p] * rf.x;
-                cg[p] = lg[p] * rf.y;
-                cb[p] = lb[p] * rf.z;
-            }
-        }
-        if (it + 1u < A.depth) {  // renderer.rs:67 (i < limit)
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                const bool on = (alive >> p) & 1u;
-                const float4 s = A.sph_r[on ? best_i[p] : 0];
-                float nx = ox[p] - s.x, ny = oy[p] - s.y, nz = oz[p] - s.z;  // renderer.rs:68 — normal at the OLD origin
-                unit3(nx, ny, nz);
-                const float dn = dot3_ref(dx[p], dy[p], dz[p], nx, ny, nz);  // object/mod.rs:72
-                const float two_dn = 2.0f * dn;
-                float ex = dx[p] - two_dn * nx, ey = dy[p] - two_dn * ny, ez = dz[p] - two_dn * nz;
-                unit3(ex, ey, ez);
-                if (on) {
-                    dx[p] = ex; dy[p] = ey; dz[p] = ez;
-                    ox[p] = hx[p]; oy[p] = hy[p]; oz[p] = hz[p];  // renderer.rs:70
-                }
+        for (int p = 0; p < P; ++p) {  // light/point.rs:25-30
+            const float vx = hx[p] - lp.x, vy = hy[p] - lp.y, vz = hz[p] - lp.z;
+            const float dist = sqrtf(dot3_ref(vx, vy, vz, vx, vy, vz));
+            const float in = lp.w / (dist * dist);
+            bool some = !(in <= 1.1920929e-7f);
+            if (shadows && ((alive >> p) & 1u)) some = some && !((A.rec_occ[(size_t)(l >> 5) * cap + rec[p]] >> (l & 31)) & 1u);
+            if (some) {
+                lr[p] = lr[p] + in * lc.x;
+                lg[p] = lg[p] + in * lc.y;
+                lb[p] = lb[p] + in * lc.z;
             }
         }
     }
-    if (sc.part != 0) return;  // the group's waves hold identical colours; one of them stores
 #pragma unroll
-    for (int p = 0; p < P; ++p)
-        if ((valid >> p) & 1u) store_pixel(A, pix[p], cr[p], cg[p], cb[p]);
+    for (int p = 0; p < P; ++p) {
+        const bool on = (alive >> p) & 1u;
+        const float4 rf = A.refl[on ? best_i[p] : 0];
+        cr[p] = lr[p] * rf.x;  // renderer.rs:66
+        cg[p] = lg[p] * rf.y;
+        cb[p] = lb[p] * rf.z;
+    }
+    if (last) {
+#pragma unroll
+        for (int p = 0; p < P; ++p)
+            if ((alive >> p) & 1u) store_pixel(A, pix[p], cr[p], cg[p], cb[p]);
+        return;
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const bool on = (alive >> p) & 1u;
+        const float4 s = A.sph_r[on ? best_i[p] : 0];
+        float nx = ox[p] - s.x, ny = oy[p] - s.y, nz = oz[p] - s.z;  // renderer.rs:68 — normal at the OLD origin
+        unit3(nx, ny, nz);
+        const float dn = dot3_ref(dx[p], dy[p], dz[p], nx, ny, nz);  // object/mod.rs:72
+        const float two_dn = 2.0f * dn;
+        float ex = dx[p] - two_dn * nx, ey = dy[p] - two_dn * ny, ez = dz[p] - two_dn * nz;
+        unit3(ex, ey, ez);
+        dx[p] = ex; dy[p] = ey; dz[p] = ez;
+        ox[p] = hx[p]; oy[p] = hy[p]; oz[p] = hz[p];  // renderer.rs:70
+    }
+    trace_general<P>(A, s_buf, tid, alive, ox, oy, oz, dx, dy, dz, best_t, best_i);  // uniform over the workgroup (barriers inside)
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        if (!((alive >> p) & 1u)) continue;
+        const uint32_t r = rec[p];
+        A.rec_idx[r] = best_i[p];
+        if (best_i[p] < 0) {
+            store_pixel(A, pix[p], cr[p], cg[p], cb[p]);  // every later iteration misses identically: the colour is final
+        } else {
+            A.rec_t[r] = best_t[p];
+            A.rec_state[kStOx * cap + r] = ox[p]; A.rec_state[kStOy * cap + r] = oy[p]; A.rec_state[kStOz * cap + r] = oz[p];
+            A.rec_state[kStDx * cap + r] = dx[p]; A.rec_state[kStDy * cap + r] = dy[p]; A.rec_state[kStDz * cap + r] = dz[p];
+            A.rec_state[kStCr * cap + r] = cr[p]; A.rec_state[kStCg * cap + r] = cg[p]; A.rec_state[kStCb * cap + r] = cb[p];
+        }
+    }
 }
 
 inline bool is_general(const RenderArgs& a) { return a.depth > 1u || (a.flags & RT_SHADOWS) != 0u; }
 
 constexpr int kB = 8;       // spheres per wave vote in the primary loop (sweep in profiles/r01_tuning.md)
-constexpr int kShadeP = 2;  // records per lane in shade_general_kernel
+constexpr int kShadeP = 2;  // records per lane in shade_iter_kernel
+constexpr int kMaskP = 4;   // shadow rays per lane in shadow_mask_kernel
 
 }  // namespace
 
@@ -772,29 +806,60 @@ hipError_t launch_primary(RenderArgs a, hipStream_t stream)
 hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
 {
     if (args.y1 <= args.y0 || args.w == 0) return hipSuccess;
-    const uint32_t rows = args.y1 - args.y0;
-    if (!is_general(args)) {
-        return launch_primary<false>(args, stream);
-    }
-    if (!args.rec_count || !args.rec_pix || !args.rec_idx || !args.rec_t) return hipErrorInvalidValue;
+    if (!is_general(args)) return launch_primary<false>(args, stream);
+
+    const bool shadows = (args.flags & RT_SHADOWS) != 0u && args.n_lights > 0;
+    const uint64_t npix = (uint64_t)(args.y1 - args.y0) * args.w;
+    if (!args.rec_count || !args.rec_pix || !args.rec_idx || !args.rec_t || args.rec_cap < npix) return hipErrorInvalidValue;
+    if ((args.depth > 1u && !args.rec_state) || (shadows && !args.rec_occ)) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(args.rec_count, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     if ((e = launch_primary<true>(args, stream)) != hipSuccess) return e;
-    // sized for the worst case (every pixel hit); workgroups past the record count exit at once, so no host round trip is needed
-    const uint64_t npix = (uint64_t)rows * args.w;
-    // Few records (a row band of a multi-GPU split): 4 waves share each record group so that there are 4x more, 4x shorter
-    // workgroups (C5 band of 270 rows: 9.6 -> 8.3 ms); a full frame has enough workgroups and is faster without the redundancy
-    // (C5 full frame 19.0 vs 20.9 ms).  The record count itself lives on the device, so the choice goes by the band's pixel count.
-    if (npix < 2500000ull) {
-        const uint32_t per_wg = (kWaves / 4) * 64 * kShadeP;
-        hipLaunchKernelGGL((shade_general_kernel<kShadeP, 4>), dim3((uint32_t)((npix + per_wg - 1) / per_wg)), dim3(kWaves * 64), 0, stream, args);
-    } else {
-        const uint32_t per_wg = kWaves * 64 * kShadeP;
-        hipLaunchKernelGGL((shade_general_kernel<kShadeP, 1>), dim3((uint32_t)((npix + per_wg - 1) / per_wg)), dim3(kWaves * 64), 0, stream, args);
+
+    // The record count lives on the device: the grids below are sized for the worst case (every pixel of the band hit) or persistent,
+    // and workgroups with nothing to do leave at once — no host round trip between the launches.
+    uint32_t mask_slots = 0;
+    if (shadows) {
+        static uint32_t cache[64] = {};
+        int dev = 0, cus = 0, per_cu = 0;
+        if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+        if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        if (cache[dev] == 0) {
+            if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+            if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, shadow_mask_kernel<kMaskP, kShadowB, kShadowChunk>, kWaves * 64, 0)) != hipSuccess) return e;
+            if (cus <= 0 || per_cu <= 0) return hipErrorInvalidValue;
+            cache[dev] = (uint32_t)cus * (uint32_t)per_cu;
+        }
+        mask_slots = cache[dev];
     }
-    return hipGetLastError();
+    RenderArgs a = args;
+    const uint32_t shade_wgs = (uint32_t)((npix + kWaves * 64 * kShadeP - 1) / (kWaves * 64 * kShadeP));
+    const uint32_t occ_words = ((uint32_t)args.n_lights + 31u) / 32u;
+    for (uint32_t it = 0; it < args.depth; ++it) {  // renderer.rs:46
+        a.iter = it;
+        if (shadows) {
+            if ((e = hipMemsetAsync(a.rec_occ, 0, (size_t)occ_words * a.rec_cap * sizeof(uint32_t), stream)) != hipSuccess) return e;
+            const uint64_t worst_tiles = (npix + kWaves * 64 * kMaskP - 1) / (kWaves * 64 * kMaskP) * (uint64_t)args.n_lights;
+            const uint32_t grid = worst_tiles < mask_slots ? (uint32_t)worst_tiles : mask_slots;
+            hipLaunchKernelGGL((shadow_mask_kernel<kMaskP, kShadowB, kShadowChunk>), dim3(grid), dim3(kWaves * 64), 0, stream, a);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL((shade_iter_kernel<kShadeP>), dim3(shade_wgs), dim3(kWaves * 64), 0, stream, a);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
-const char* render_kernel_name(const RenderArgs& args) { return is_general(args) ? "render_kernel<emit> + shade_general_kernel" : "render_kernel<primary>"; }
+void render_scratch_layout(const RenderArgs& args, bool& need_state, uint32_t& occ_words)
+{
+    need_state = args.depth > 1u;
+    occ_words = ((args.flags & RT_SHADOWS) != 0u && args.n_lights > 0) ? ((uint32_t)args.n_lights + 31u) / 32u : 0u;
+}
+
+const char* render_kernel_name(const RenderArgs& args)
+{
+    if (!is_general(args)) return "render_kernel<primary>";
+    return (args.flags & RT_SHADOWS) ? "render_kernel<emit> + shadow_mask_kernel + shade_iter_kernel" : "render_kernel<emit> + shade_iter_kernel";
+}
 
 }  // namespace rtamd

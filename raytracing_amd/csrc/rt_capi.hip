@@ -36,7 +36,8 @@ struct rt_ctx {
     size_t d_hit_bytes = 0;
     // dense hit records for the general path: [count (16 B) | pix | idx | t], capacity in pixels
     void* d_rec = nullptr;
-    size_t rec_capacity = 0;
+    size_t rec_capacity = 0;   // records
+    size_t rec_planes = 0;     // 4-byte planes of rec_capacity entries allocated after the 16-byte counter
     // tile-queue counters of the persistent primary kernel: a ring of slots (64 B apart), one per launch in flight
     uint32_t* d_tile_ctr = nullptr;
     uint32_t tile_slot = 0;
@@ -235,21 +236,35 @@ int32_t rt_render_rows_device(rt_ctx* c, const float m[16], uint32_t w, uint32_t
     a.rec_count = nullptr; a.rec_pix = nullptr; a.rec_idx = nullptr; a.rec_t = nullptr;
     a.tile_ctr = c->d_tile_ctr + (size_t)(c->tile_slot++ % kTileSlots) * 16;
     a.strips = a.tiles4 = a.tiles2 = a.tiles1 = a.rows4 = a.rows2 = 0;
+    a.rec_cap = 0; a.iter = 0; a.rec_state = nullptr; a.rec_occ = nullptr;
     if (render_needs_records(a)) {
+        // scratch: [count (16 B) | pix | idx | t | 9 state planes (depth > 1) | occlusion planes (RT_SHADOWS)], planes of rec_capacity words
         const size_t npix = (size_t)(y1 - y0) * w;
-        if (npix > c->rec_capacity) {  // grow the scratch (the previous launches that used it must be finished first)
+        bool need_state = false;
+        uint32_t occ_words = 0;
+        render_scratch_layout(a, need_state, occ_words);
+        const size_t planes = 3 + (need_state ? 9 : 0) + occ_words;
+        if (npix > c->rec_capacity || planes > c->rec_planes) {  // grow (the previous launches that used it must be finished first)
+            const size_t cap = npix > c->rec_capacity ? npix : c->rec_capacity;
+            const size_t pl = planes > c->rec_planes ? planes : c->rec_planes;
             RT_HIP(c, hipDeviceSynchronize());
             if (c->d_rec) RT_HIP(c, hipFree(c->d_rec));
             c->d_rec = nullptr;
             c->rec_capacity = 0;
-            RT_HIP(c, hipMalloc(&c->d_rec, 16 + npix * 12));
-            c->rec_capacity = npix;
+            c->rec_planes = 0;
+            RT_HIP(c, hipMalloc(&c->d_rec, 16 + cap * pl * 4));
+            c->rec_capacity = cap;
+            c->rec_planes = pl;
         }
         char* base = static_cast<char*>(c->d_rec);
+        const size_t plane = c->rec_capacity * 4;
+        a.rec_cap = (uint32_t)c->rec_capacity;
         a.rec_count = reinterpret_cast<uint32_t*>(base);
         a.rec_pix = reinterpret_cast<uint32_t*>(base + 16);
-        a.rec_idx = reinterpret_cast<int32_t*>(base + 16 + c->rec_capacity * 4);
-        a.rec_t = reinterpret_cast<float*>(base + 16 + c->rec_capacity * 8);
+        a.rec_idx = reinterpret_cast<int32_t*>(base + 16 + plane);
+        a.rec_t = reinterpret_cast<float*>(base + 16 + 2 * plane);
+        if (need_state) a.rec_state = reinterpret_cast<float*>(base + 16 + 3 * plane);
+        if (occ_words) a.rec_occ = reinterpret_cast<uint32_t*>(base + 16 + (3 + (need_state ? 9 : 0)) * plane);
     }
     RT_HIP(c, hipEventRecord(c->ev0, st));
     RT_HIP(c, launch_render(a, st));
