@@ -740,7 +740,10 @@ inline bool is_general(const RenderArgs& a) { return a.depth > 1u || (a.flags & 
 
 constexpr int kB = 8;       // spheres per wave vote in the primary loop (sweep in profiles/r01_tuning.md)
 constexpr int kShadeP = 2;  // records per lane in shade_iter_kernel
-constexpr int kMaskP = 4;   // shadow rays per lane in shadow_mask_kernel
+#ifndef RT_MASK_P
+#define RT_MASK_P 4
+#endif
+constexpr int kMaskP = RT_MASK_P;   // shadow rays per lane in shadow_mask_kernel
 
 }  // namespace
 

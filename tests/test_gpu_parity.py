@@ -315,3 +315,33 @@ def test_fuzz_scenes_cameras_modes(gpu_ctx, oracle):
         ref, ref_hit = oracle.render(objs, lights, m, w, h, depth=depth, flags=flags & 1, channels=3 if flags & 2 else 4, want_hit_idx=True)
         _assert_same(gpu, ref, f"fuzz case {case}: {w}x{h} n={n} l={nl} depth={depth} flags={flags}")
         assert np.array_equal(hit, ref_hit), f"fuzz case {case}: hit index plane"
+
+
+def test_wavefront_many_lights_depth_and_bands(gpu_ctx, oracle):
+    """General-ray kernels (shadow_mask_kernel + shade_iter_kernel): more than 32 lights (two occlusion words per record) with ambient
+    lights in between, depth 3 with shadows, row bands, and the scratch planes reused across calls with different needs."""
+    w, h = 160, 96
+    objs, pts = scenegen.generate(w, h, 96, 37, seed=33)
+    n = pts.n + 3
+    ins = [0, 17, 36]  # ambient lights in front, in the middle, near the end of the list
+    kind = np.zeros(n, np.uint8)
+    px, py, pz, cr, cg, cb, it = (np.zeros(n, np.float32) for _ in range(7))
+    src = 0
+    for i in range(n):
+        if i in ins:
+            kind[i] = 1
+            cr[i], cg[i], cb[i] = 0.01, 0.02, 0.03
+        else:
+            px[i], py[i], pz[i], cr[i], cg[i], cb[i], it[i] = (pts.px[src], pts.py[src], pts.pz[src], pts.cr[src], pts.cg[src], pts.cb[src],
+                                                               pts.intensity[src])
+            src += 1
+    lights = capi.FlatLights(px, py, pz, cr, cg, cb, it, kind=kind)
+    gpu_ctx.scene_upload(objs, lights)
+    m = _cam(oracle, w, h)
+    for depth, flags in ((1, capi.RT_SHADOWS), (3, 0), (3, capi.RT_SHADOWS), (1, 0), (2, capi.RT_SHADOWS)):
+        gpu = gpu_ctx.render(m, w, h, depth, flags)
+        ref = oracle.render(objs, lights, m, w, h, depth=depth, flags=1 if flags else 0)
+        _assert_same(gpu, ref, f"40 lights depth {depth} flags {flags}")
+    ref = oracle.render(objs, lights, m, w, h, depth=3, flags=1)
+    parts = [gpu_ctx.render_rows(m, w, h, a, b, 3, capi.RT_SHADOWS)[0] for a, b in ((0, 31), (31, 32), (32, 96))]
+    _assert_same(np.concatenate(parts), ref, "bands, depth 3, shadows")
