@@ -254,7 +254,7 @@ def test_c4_scene_reduced_resolution(gpu_ctx, oracle):
 
 
 def test_general_path_rgb8_and_hit_idx(gpu_ctx, oracle):
-    """depth 2 + shadows through the two-launch path with RGB8 output and the hit-index plane (both written by the emit kernel + shade kernel)."""
+    """depth 2 + shadows through the general-ray kernels with RGB8 output and the hit-index plane (written by the emit kernel)."""
     w, h = 150, 90
     objs, lights = scenegen.generate(w, h, 120, 3, seed=44)
     gpu_ctx.scene_upload(objs, lights)
@@ -272,7 +272,7 @@ def test_general_path_rgb8_and_hit_idx(gpu_ctx, oracle):
 
 
 def test_c3_full_size_general_path(gpu_ctx, oracle):
-    """Full 4K frame through the two-launch path (the large-launch geometry of shade_general_kernel): depth 2 with shadows, every 60th row."""
+    """Full 4K frame through the general-ray kernels (emit, shadow mask, per-iteration shading): depth 2 with shadows, every 60th row."""
     w, h, objs, lights = scenegen.config("C3")
     gpu_ctx.scene_upload(objs, lights)
     m = _cam(oracle, w, h)
@@ -345,3 +345,27 @@ def test_wavefront_many_lights_depth_and_bands(gpu_ctx, oracle):
     ref = oracle.render(objs, lights, m, w, h, depth=3, flags=1)
     parts = [gpu_ctx.render_rows(m, w, h, a, b, 3, capi.RT_SHADOWS)[0] for a, b in ((0, 31), (31, 32), (32, 96))]
     _assert_same(np.concatenate(parts), ref, "bands, depth 3, shadows")
+
+
+def test_c4_c5_full_size_sampled_rows(gpu_ctx, oracle):
+    """Configs 4 and 5 at BASELINE.json's full sizes: C4 (7680x4320, 8192 spheres, 8 lights) every 540th row, C5 (3840x2160,
+    4096 spheres, 32 lights) with the shadow extension every 360th row, against the oracle; whole-frame properties on the rest."""
+    w, h, objs, lights = scenegen.config("C4")
+    gpu_ctx.scene_upload(objs, lights)
+    m = _cam(oracle, w, h)
+    gpu, hit = gpu_ctx.render_rows(m, w, h, 0, h, 1, 0, want_hit_idx=True)
+    ref, ref_hit = oracle.render(objs, lights, m, w, h, row_step=540, want_hit_idx=True)
+    _assert_same(gpu[::540], ref[::540], "C4 sampled rows")
+    assert np.array_equal(hit[::540], ref_hit[::540])
+    assert (gpu[..., 3] == 255).all() and not gpu[hit < 0][:, :3].any() and hit.max() < objs.n
+    del gpu, hit
+    w, h, objs, lights = scenegen.config("C5")
+    gpu_ctx.scene_upload(objs, lights)
+    m = _cam(oracle, w, h)
+    lit = gpu_ctx.render(m, w, h, 1, 0)
+    shadowed = gpu_ctx.render(m, w, h, 1, capi.RT_SHADOWS)
+    ref = oracle.render(objs, lights, m, w, h, row_step=360, flags=1)
+    _assert_same(shadowed[::360], ref[::360], "C5 shadows sampled rows")
+    # occlusion only removes light: no channel gets brighter, background stays black, something does get darker
+    assert (shadowed[..., :3] <= lit[..., :3]).all()
+    assert (shadowed[..., :3] < lit[..., :3]).any()
