@@ -16,6 +16,7 @@
 #ifndef RT_MI355X_H
 #define RT_MI355X_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -112,6 +113,16 @@ int32_t rt_render_rows(rt_ctx* ctx, const float m[16], uint32_t w, uint32_t h, u
  */
 int32_t rt_render_rows_device(rt_ctx* ctx, const float m[16], uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t depth, uint32_t flags,
                               void* d_out, void* d_hit_idx, void* stream);
+
+/*
+ * Framebuffer::new (display.rs:46-61) allocates the pixel store the host entry points write into (a raw allocation turned into
+ * an ImageBuffer with from_raw, display.rs:50-57).  Taking that store from rt_host_alloc (page-locked host memory, hipHostMalloc)
+ * lets rt_render / rt_render_rows copy the frame at PCIe rate and overlap the copy of one row chunk with the render of the
+ * next; with ordinary (pageable) memory the copy goes through the driver's bounce buffers and blocks.  Optional.
+ * (hipHostRegister of an existing allocation is refused on the pool this was developed on, hence alloc/free.)
+ */
+int32_t rt_host_alloc(rt_ctx* ctx, size_t bytes, void** out);
+int32_t rt_host_free(rt_ctx* ctx, void* host_ptr);
 
 /* Elapsed GPU time (ms, hipEvent) of the kernels of the most recent rt_render* on this ctx; synchronises on its end event. */
 int32_t rt_last_kernel_ms(rt_ctx* ctx, float* ms);

@@ -28,7 +28,7 @@ LIB_PATH = os.environ.get("RT_MI355X_LIB") or os.path.join(os.path.dirname(os.pa
 EXPORTS = (
     "rt_version", "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_camera_transform", "rt_camera_default",
     "rt_scene_upload", "rt_render", "rt_render_rows", "rt_render_rows_device", "rt_last_kernel_ms",
-    "rt_debug_prepare_spheres",
+    "rt_debug_prepare_spheres", "rt_host_alloc", "rt_host_free",
 )
 
 _f32p = C.POINTER(C.c_float)
@@ -78,6 +78,8 @@ def load() -> C.CDLL:
     lib.rt_camera_transform.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, _f32p]
     lib.rt_camera_default.argtypes = [_f32p, _f32p, _f32p]
     lib.rt_scene_upload.argtypes = [vp, C.POINTER(RtObjects), C.POINTER(RtLights)]
+    lib.rt_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    lib.rt_host_free.argtypes = [vp, vp]
     lib.rt_render.argtypes = [vp, _f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
     lib.rt_render_rows.argtypes = [vp, _f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
     lib.rt_render_rows_device.argtypes = [vp, _f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
@@ -172,6 +174,7 @@ class Context:
         if rc != RT_OK:
             raise RtError(rc, (self._lib.rt_last_error(None) or b"").decode())
         self.device_id = device_id
+        self._pinned = {}
 
     def _check(self, rc: int):
         if rc != RT_OK:
@@ -198,16 +201,34 @@ class Context:
         o, l = objs.c_struct(), lights.c_struct()
         self._check(self._lib.rt_scene_upload(self._h, C.byref(o), C.byref(l)))
 
-    def render(self, m: Sequence[float], w: int, h: int, depth: int = 1, flags: int = 0) -> np.ndarray:
-        return self.render_rows(m, w, h, 0, h, depth, flags)[0]
+    def render(self, m: Sequence[float], w: int, h: int, depth: int = 1, flags: int = 0, out: Optional[np.ndarray] = None) -> np.ndarray:
+        return self.render_rows(m, w, h, 0, h, depth, flags, out=out)[0]
 
-    def render_rows(self, m, w: int, h: int, y0: int, y1: int, depth: int = 1, flags: int = 0, want_hit_idx: bool = False):
+    def host_frame(self, shape) -> np.ndarray:
+        """A page-locked uint8 frame store (rt_host_alloc) as a numpy array; render(..., out=frame) then copies at PCIe rate.
+        Release it with host_free(frame) before closing the context."""
+        n = int(np.prod(shape))
+        p = C.c_void_p()
+        self._check(self._lib.rt_host_alloc(self._h, n, C.byref(p)))
+        arr = np.ctypeslib.as_array((C.c_uint8 * n).from_address(p.value)).reshape(shape)
+        self._pinned[arr.ctypes.data] = p.value
+        return arr
+
+    def host_free(self, arr: np.ndarray) -> None:
+        p = self._pinned.pop(arr.ctypes.data)
+        self._check(self._lib.rt_host_free(self._h, C.c_void_p(p)))
+
+    def render_rows(self, m, w: int, h: int, y0: int, y1: int, depth: int = 1, flags: int = 0, want_hit_idx: bool = False,
+                    out: Optional[np.ndarray] = None):
         m = _f32(m)
         if m.size != 16:
             raise ValueError("camera matrix must have 16 entries")
         ch = 3 if (flags & RT_OUT_RGB8) else 4
         rows = max(0, y1 - y0)
-        out = np.zeros((rows, w, ch), dtype=np.uint8)
+        if out is None:
+            out = np.zeros((rows, w, ch), dtype=np.uint8)
+        elif out.dtype != np.uint8 or out.shape != (rows, w, ch) or not out.flags.c_contiguous:
+            raise ValueError(f"out must be a C-contiguous uint8 array of shape {(rows, w, ch)}")
         hit = np.full((rows, w), -2, dtype=np.int32) if want_hit_idx else None
         self._check(self._lib.rt_render_rows(self._h, m.ctypes.data_as(_f32p), w, h, y0, y1, depth, flags,
                                              out.ctypes.data_as(C.c_void_p), hit.ctypes.data_as(C.c_void_p) if hit is not None else None))

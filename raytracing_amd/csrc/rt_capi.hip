@@ -16,8 +16,9 @@ using namespace rtamd;
 
 struct rt_ctx {
     int device = -1;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, copy_stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_chunk[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timed = false;
     std::string err;
     // device copies of the prepared scene
@@ -116,7 +117,10 @@ int32_t rt_ctx_create(rt_ctx** out, int32_t device_id)
     if (!c) return fail(nullptr, RT_ERR_HIP, "out of host memory");
     c->device = device_id;
     if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->ev_chunk[0], hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&c->ev_chunk[1], hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->ev_chunk[2], hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&c->ev_chunk[3], hipEventDisableTiming)) != hipSuccess ||
         (e = hipMalloc(reinterpret_cast<void**>(&c->d_tile_ctr), kTileSlots * 64)) != hipSuccess ||
         (e = hipMemset(c->d_tile_ctr, 0, kTileSlots * 64)) != hipSuccess) {
         int32_t rc = fail_hip(nullptr, e, "context setup");
@@ -132,6 +136,7 @@ int32_t rt_ctx_destroy(rt_ctx* c)
     if (!c) return RT_OK;
     if (c->device >= 0) (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     if (c->d_scene) (void)hipFree(c->d_scene);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_hit) (void)hipFree(c->d_hit);
@@ -139,6 +144,9 @@ int32_t rt_ctx_destroy(rt_ctx* c)
     if (c->d_tile_ctr) (void)hipFree(c->d_tile_ctr);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (hipEvent_t e : c->ev_chunk)
+        if (e) (void)hipEventDestroy(e);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return RT_OK;
@@ -218,14 +226,12 @@ static int32_t check_render_args(rt_ctx* c, const float* m, uint32_t w, uint32_t
     return RT_OK;
 }
 
-int32_t rt_render_rows_device(rt_ctx* c, const float m[16], uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t depth, uint32_t flags,
-                              void* d_out, void* d_hit_idx, void* stream)
+}  // extern "C"
+
+// Enqueue the kernels of the band [y0, y1) on `st` (arguments already checked, ctx's device current).
+static int32_t enqueue_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t depth, uint32_t flags,
+                            void* d_out, void* d_hit_idx, hipStream_t st)
 {
-    int32_t rc = check_render_args(c, m, w, h, y0, y1, depth, flags);
-    if (rc != RT_OK) return rc;
-    if (y1 > y0 && !d_out) return fail(c, RT_ERR_INVALID, "output pointer is null");
-    RT_HIP(c, hipSetDevice(c->device));
-    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : c->stream;
     RenderArgs a;
     std::memcpy(a.m, m, sizeof(a.m));
     a.w = w; a.h = h; a.y0 = y0; a.y1 = y1; a.depth = depth; a.flags = flags;
@@ -266,8 +272,23 @@ int32_t rt_render_rows_device(rt_ctx* c, const float m[16], uint32_t w, uint32_t
         if (need_state) a.rec_state = reinterpret_cast<float*>(base + 16 + 3 * plane);
         if (occ_words) a.rec_occ = reinterpret_cast<uint32_t*>(base + 16 + (3 + (need_state ? 9 : 0)) * plane);
     }
-    RT_HIP(c, hipEventRecord(c->ev0, st));
     RT_HIP(c, launch_render(a, st));
+    return RT_OK;
+}
+
+extern "C" {
+
+int32_t rt_render_rows_device(rt_ctx* c, const float m[16], uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t depth, uint32_t flags,
+                              void* d_out, void* d_hit_idx, void* stream)
+{
+    int32_t rc = check_render_args(c, m, w, h, y0, y1, depth, flags);
+    if (rc != RT_OK) return rc;
+    if (y1 > y0 && !d_out) return fail(c, RT_ERR_INVALID, "output pointer is null");
+    RT_HIP(c, hipSetDevice(c->device));
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    RT_HIP(c, hipEventRecord(c->ev0, st));
+    rc = enqueue_rows(c, m, w, h, y0, y1, depth, flags, d_out, d_hit_idx, st);
+    if (rc != RT_OK) return rc;
     RT_HIP(c, hipEventRecord(c->ev1, st));
     c->timed = true;
     return RT_OK;
@@ -297,10 +318,28 @@ int32_t rt_render_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h, uin
         RT_HIP(c, hipMalloc(&c->d_hit, npix * 4));
         c->d_hit_bytes = npix * 4;
     }
-    rc = rt_render_rows_device(c, m, w, h, y0, y1, depth, flags, c->d_out, hit_idx_host ? c->d_hit : nullptr, nullptr);
-    if (rc != RT_OK) return rc;
-    RT_HIP(c, hipMemcpyAsync(out_host, c->d_out, bytes, hipMemcpyDeviceToHost, c->stream));
-    if (hit_idx_host) RT_HIP(c, hipMemcpyAsync(hit_idx_host, c->d_hit, npix * 4, hipMemcpyDeviceToHost, c->stream));
+    // A large band goes out in row chunks: the copy of chunk k to the host (copy stream) overlaps the render of chunk k+1
+    // (ctx stream).  Chunks are row bands, so the image is the single-launch image byte for byte.
+    const size_t bpp = (flags & RT_OUT_RGB8) ? 3 : 4;
+    const uint32_t rows = y1 - y0;
+    const uint32_t n_chunks = npix >= (2u << 20) ? 4u : 1u;
+    RT_HIP(c, hipEventRecord(c->ev0, c->stream));
+    for (uint32_t k = 0; k < n_chunks; ++k) {
+        const uint32_t r0 = (uint32_t)((uint64_t)rows * k / n_chunks), r1 = (uint32_t)((uint64_t)rows * (k + 1) / n_chunks);
+        if (r1 == r0) continue;
+        const size_t off = (size_t)r0 * w;
+        rc = enqueue_rows(c, m, w, h, y0 + r0, y0 + r1, depth, flags, static_cast<char*>(c->d_out) + off * bpp,
+                          hit_idx_host ? static_cast<char*>(c->d_hit) + off * 4 : nullptr, c->stream);
+        if (rc != RT_OK) return rc;
+        RT_HIP(c, hipEventRecord(c->ev_chunk[k], c->stream));
+        RT_HIP(c, hipStreamWaitEvent(c->copy_stream, c->ev_chunk[k], 0));
+        RT_HIP(c, hipMemcpyAsync(out_host + off * bpp, static_cast<char*>(c->d_out) + off * bpp, (size_t)(r1 - r0) * w * bpp, hipMemcpyDeviceToHost, c->copy_stream));
+        if (hit_idx_host)
+            RT_HIP(c, hipMemcpyAsync(hit_idx_host + off, static_cast<char*>(c->d_hit) + off * 4, (size_t)(r1 - r0) * w * 4, hipMemcpyDeviceToHost, c->copy_stream));
+    }
+    RT_HIP(c, hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
+    RT_HIP(c, hipStreamSynchronize(c->copy_stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     return RT_OK;
 }
@@ -308,6 +347,26 @@ int32_t rt_render_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h, uin
 int32_t rt_render(rt_ctx* c, const float m[16], uint32_t w, uint32_t h, uint32_t depth, uint32_t flags, uint8_t* out_host)
 {
     return rt_render_rows(c, m, w, h, 0, h, depth, flags, out_host, nullptr);
+}
+
+int32_t rt_host_alloc(rt_ctx* c, size_t bytes, void** out)
+{
+    if (!c) return RT_ERR_INVALID;
+    if (!out || bytes == 0) return fail(c, RT_ERR_INVALID, "rt_host_alloc: empty request");
+    *out = nullptr;
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return RT_OK;
+}
+
+int32_t rt_host_free(rt_ctx* c, void* p)
+{
+    if (!c) return RT_ERR_INVALID;
+    if (!p) return RT_OK;
+    RT_HIP(c, hipSetDevice(c->device));
+    RT_HIP(c, hipStreamSynchronize(c->copy_stream));  // no copy of this ctx may still target the block
+    RT_HIP(c, hipHostFree(p));
+    return RT_OK;
 }
 
 int32_t rt_last_kernel_ms(rt_ctx* c, float* ms)

@@ -54,6 +54,8 @@ extern "C" {
                           out_host: *mut u8, hit_idx_host: *mut i32) -> i32;
     pub fn rt_render_rows_device(ctx: *mut rt_ctx, m: *const f32, w: u32, h: u32, y0: u32, y1: u32, depth: u32, flags: u32,
                                  d_out: *mut c_void, d_hit_idx: *mut c_void, stream: *mut c_void) -> i32;
+    pub fn rt_host_alloc(ctx: *mut rt_ctx, bytes: usize, out: *mut *mut c_void) -> i32;
+    pub fn rt_host_free(ctx: *mut rt_ctx, host_ptr: *mut c_void) -> i32;
     pub fn rt_last_kernel_ms(ctx: *mut rt_ctx, ms: *mut f32) -> i32;
     pub fn rt_debug_prepare_spheres(objects: *const rt_objects, filt: *mut f32, cls: *mut u8) -> i32;
 }

@@ -369,3 +369,40 @@ def test_c4_c5_full_size_sampled_rows(gpu_ctx, oracle):
     # occlusion only removes light: no channel gets brighter, background stays black, something does get darker
     assert (shadowed[..., :3] <= lit[..., :3]).all()
     assert (shadowed[..., :3] < lit[..., :3]).any()
+
+
+def test_host_store_pinned_and_chunked_copy(gpu_ctx, oracle):
+    """rt_render_rows into a caller-provided store: a frame large enough for the chunked render/copy pipeline (>= 2 Mpixel), in
+    pageable memory and in a page-locked store from rt_host_alloc, RGBA8 and RGB8, with the hit-index plane — same bytes as the
+    device-resident path (one launch) and, on sampled rows, as the oracle."""
+    import torch
+    w, h = 2048, 1100
+    objs, lights = scenegen.generate(w, h, 300, 3, seed=77)
+    gpu_ctx.scene_upload(objs, lights)
+    m = _cam(oracle, w, h)
+    dev = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    gpu_ctx.render_rows_device(m, w, h, 0, h, 1, 0, dev.data_ptr())
+    torch.cuda.synchronize()
+    one_launch = dev.cpu().numpy()
+    ref = oracle.render(objs, lights, m, w, h, row_step=100)
+    _assert_same(one_launch[::100], ref[::100], "device-resident frame")
+    pageable = np.zeros((h, w, 4), np.uint8)
+    got, hit = gpu_ctx.render_rows(m, w, h, 0, h, 1, 0, want_hit_idx=True, out=pageable)
+    assert got is pageable
+    _assert_same(pageable, one_launch, "chunked copy into pageable memory")
+    assert ((hit >= 0) == (one_launch[..., :3].sum(axis=-1) > 0)).mean() > 0.99  # hit pixels are lit (a few may quantise to black)
+    pinned = gpu_ctx.host_frame((h, w, 4))
+    try:
+        gpu_ctx.render(m, w, h, 1, 0, out=pinned)
+        _assert_same(pinned, one_launch, "chunked copy into the rt_host_alloc store")
+        pinned[:] = 0
+        gpu_ctx.render(m, w, h, 2, capi.RT_SHADOWS, out=pinned)  # general-ray kernels chunk by chunk
+        gen = oracle.render(objs, lights, m, w, h, row_step=100, depth=2, flags=1)
+        _assert_same(pinned[::100], gen[::100], "chunked general path")
+    finally:
+        gpu_ctx.host_free(pinned)
+    rgb = np.zeros((h, w, 3), np.uint8)
+    gpu_ctx.render(m, w, h, 1, capi.RT_OUT_RGB8, out=rgb)
+    _assert_same(rgb, one_launch[..., :3], "chunked RGB8")
+    with pytest.raises(ValueError):
+        gpu_ctx.render(m, w, h, 1, 0, out=rgb)
