@@ -843,6 +843,7 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
         if (shadows) {
             if ((e = hipMemsetAsync(a.rec_occ, 0, (size_t)occ_words * a.rec_cap * sizeof(uint32_t), stream)) != hipSuccess) return e;
             const uint64_t worst_tiles = (npix + kWaves * 64 * kMaskP - 1) / (kWaves * 64 * kMaskP) * (uint64_t)args.n_lights;
+            if (worst_tiles >= (1ull << 32)) return hipErrorInvalidValue;  // the tile queue counts in 32 bits
             const uint32_t grid = worst_tiles < mask_slots ? (uint32_t)worst_tiles : mask_slots;
             hipLaunchKernelGGL((shadow_mask_kernel<kMaskP, kShadowB, kShadowChunk>), dim3(grid), dim3(kWaves * 64), 0, stream, a);
             if ((e = hipGetLastError()) != hipSuccess) return e;
