@@ -134,6 +134,13 @@ int32_t rt_last_kernel_ms(rt_ctx* ctx, float* ms);
  */
 int32_t rt_debug_prepare_spheres(const rt_objects* objects, float* filt, uint8_t* cls);
 
+/*
+ * Host-only introspection of how a band of `rows` rows x `w` columns is cut into the tile queue of the primary kernel when the
+ * device holds `slots` resident workgroups (no device needed; used by the CPU tests): plan = {strips of 64 columns, rows in
+ * 16-row tiles, rows in 8-row tiles, number of 16-, 8- and 4-row tiles}.  See DESIGN.md §3.
+ */
+int32_t rt_debug_tile_plan(uint32_t w, uint32_t rows, uint32_t slots, uint32_t plan[6]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,7 +28,7 @@ LIB_PATH = os.environ.get("RT_MI355X_LIB") or os.path.join(os.path.dirname(os.pa
 EXPORTS = (
     "rt_version", "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_camera_transform", "rt_camera_default",
     "rt_scene_upload", "rt_render", "rt_render_rows", "rt_render_rows_device", "rt_last_kernel_ms",
-    "rt_debug_prepare_spheres", "rt_host_alloc", "rt_host_free",
+    "rt_debug_prepare_spheres", "rt_host_alloc", "rt_host_free", "rt_debug_tile_plan",
 )
 
 _f32p = C.POINTER(C.c_float)
@@ -78,6 +78,7 @@ def load() -> C.CDLL:
     lib.rt_camera_transform.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, _f32p]
     lib.rt_camera_default.argtypes = [_f32p, _f32p, _f32p]
     lib.rt_scene_upload.argtypes = [vp, C.POINTER(RtObjects), C.POINTER(RtLights)]
+    lib.rt_debug_tile_plan.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.rt_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
     lib.rt_host_free.argtypes = [vp, vp]
     lib.rt_render.argtypes = [vp, _f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
@@ -134,6 +135,15 @@ class FlatLights:
     def c_struct(self) -> RtLights:
         return RtLights(self.n, _ptr(self.kind, _u8p), _ptr(self.px, _f32p), _ptr(self.py, _f32p), _ptr(self.pz, _f32p),
                         _ptr(self.cr, _f32p), _ptr(self.cg, _f32p), _ptr(self.cb, _f32p), _ptr(self.intensity, _f32p))
+
+
+def tile_plan(w: int, rows: int, slots: int) -> dict:
+    """Host-only: the tile queue launch_render builds for a rows x w band on a device with `slots` resident workgroups."""
+    plan = (C.c_uint32 * 6)()
+    rc = load().rt_debug_tile_plan(w, rows, slots, plan)
+    if rc != RT_OK:
+        raise RtError(rc, "rt_debug_tile_plan")
+    return dict(zip(("strips", "rows4", "rows2", "tiles4", "tiles2", "tiles1"), (int(v) for v in plan)))
 
 
 def camera_transform(fov: float, z_near: float, z_far: float, aspect: float) -> np.ndarray:

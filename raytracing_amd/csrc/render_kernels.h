@@ -43,6 +43,14 @@ struct RenderArgs {
     uint32_t rows4, rows2;            // rows covered by the first two sections
 };
 
+// How launch_render cuts a band of `rows` rows x `w` columns into the tile queue of the persistent primary kernel, given the number of
+// resident workgroup slots: 64-pixel strips; the first rows4 rows in 16-row tiles, the next rows2 in 8-row tiles, the rest in 4-row tiles
+// (rows past the band's end are masked in the kernel).  Host-only; exposed for the CPU tests (rt_debug_tile_plan).
+struct TilePlan {
+    uint32_t strips, rows4, rows2, tiles4, tiles2, tiles1;
+};
+TilePlan plan_tiles(uint32_t w, uint32_t rows, uint32_t slots);
+
 // Enqueue the render of args.[y0,y1) on `stream`. Returns the HIP status of the launch.
 hipError_t launch_render(const RenderArgs& args, hipStream_t stream);
 

@@ -749,6 +749,27 @@ constexpr int kMaskP = RT_MASK_P;   // shadow rays per lane in shadow_mask_kerne
 
 bool render_needs_records(const RenderArgs& args) { return is_general(args); }
 
+TilePlan plan_tiles(uint32_t w, uint32_t rows, uint32_t slots)
+{
+    TilePlan tp;
+    tp.strips = (w + kWaves * kLX - 1) / (kWaves * kLX);
+    const uint64_t tiles16 = (uint64_t)tp.strips * ((rows + 15) / 16);
+    if (tiles16 < 2ull * slots) {
+        // a launch with few tiles (a row band of a multi-GPU split): 8-row tiles fill the chip better (profiles/r01_tuning.md)
+        tp.rows4 = 0;
+        tp.rows2 = (rows + 7) / 8 * 8;
+    } else {
+        // 16-row tiles for 85 % of the band, then 10 % in 8-row and the last 5 % in 4-row tiles (sweep in profiles/r01_tuning.md)
+        tp.rows4 = (uint32_t)((uint64_t)rows * 850 / 1000) / 16 * 16;
+        tp.rows2 = (uint32_t)((uint64_t)rows * 100 / 1000) / 8 * 8;
+    }
+    const uint32_t rest = rows > tp.rows4 + tp.rows2 ? rows - tp.rows4 - tp.rows2 : 0;
+    tp.tiles4 = tp.strips * (tp.rows4 / 16);
+    tp.tiles2 = tp.strips * (tp.rows2 / 8);
+    tp.tiles1 = tp.strips * ((rest + 3) / 4);
+    return tp;
+}
+
 namespace {
 
 // Resident workgroup slots of the current device for render_kernel<EMIT> (CUs x workgroups per CU), cached per device.
@@ -779,26 +800,13 @@ hipError_t launch_primary(RenderArgs a, hipStream_t stream)
     uint32_t slots = 0;
     hipError_t e = resident_slots<EMIT>(slots);
     if (e != hipSuccess) return e;
-    const uint32_t rows = a.y1 - a.y0;
-    a.strips = (a.w + kWaves * kLX - 1) / (kWaves * kLX);
-    const uint64_t tiles16 = (uint64_t)a.strips * ((rows + 15) / 16);
-    uint32_t rows4, rows2;
-    if (tiles16 < 2ull * slots) {
-        // a launch with few tiles (a row band of a multi-GPU split): 8-row tiles fill the chip better (profiles/r01_tuning.md)
-        rows4 = 0;
-        rows2 = (rows + 7) / 8 * 8;
-    } else {
-        // 16-row tiles for 85 % of the band, then 10 % in 8-row and the last 5 % in 4-row tiles (sweep in profiles/r01_tuning.md)
-        rows4 = (uint32_t)((uint64_t)rows * 850 / 1000) / 16 * 16;
-        rows2 = (uint32_t)((uint64_t)rows * 100 / 1000) / 8 * 8;
-        if (rows4 + rows2 > rows) rows2 = (rows - rows4) / 8 * 8;
-    }
-    const uint32_t rest = rows > rows4 + rows2 ? rows - rows4 - rows2 : 0;
-    a.rows4 = rows4;
-    a.rows2 = rows2;
-    a.tiles4 = a.strips * (rows4 / 16);
-    a.tiles2 = a.strips * (rows2 / 8);
-    a.tiles1 = a.strips * ((rest + 3) / 4);
+    const TilePlan tp = plan_tiles(a.w, a.y1 - a.y0, slots);
+    a.strips = tp.strips;
+    a.rows4 = tp.rows4;
+    a.rows2 = tp.rows2;
+    a.tiles4 = tp.tiles4;
+    a.tiles2 = tp.tiles2;
+    a.tiles1 = tp.tiles1;
     const uint32_t n_tiles = a.tiles4 + a.tiles2 + a.tiles1;
     const uint32_t grid = n_tiles < slots ? n_tiles : slots;
     hipLaunchKernelGGL((render_kernel<kB, EMIT>), dim3(grid), dim3(kWaves * 64), 0, stream, a);

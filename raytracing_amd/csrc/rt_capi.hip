@@ -100,6 +100,14 @@ int32_t rt_debug_prepare_spheres(const rt_objects* o, float* filt, uint8_t* cls)
     return RT_OK;
 }
 
+int32_t rt_debug_tile_plan(uint32_t w, uint32_t rows, uint32_t slots, uint32_t plan[6])
+{
+    if (!plan || w == 0 || slots == 0) return RT_ERR_INVALID;
+    const TilePlan tp = plan_tiles(w, rows, slots);
+    plan[0] = tp.strips; plan[1] = tp.rows4; plan[2] = tp.rows2; plan[3] = tp.tiles4; plan[4] = tp.tiles2; plan[5] = tp.tiles1;
+    return RT_OK;
+}
+
 int32_t rt_ctx_create(rt_ctx** out, int32_t device_id)
 {
     if (!out) return fail(nullptr, RT_ERR_INVALID, "rt_ctx_create: out is null");

@@ -129,3 +129,30 @@ def test_missing_library_fails_loudly():
     env = dict(os.environ, RT_MI355X_LIB="/nonexistent/librt_mi355x.so")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert "RAISED True" in out.stdout, out.stdout + out.stderr
+
+
+def test_tile_plan_covers_every_band_exactly_once():
+    """Host logic of the persistent primary kernel's tile queue: the three sections are aligned to their tile heights, follow each
+    other without gap or overlap, and together cover the band (only the last section may reach past its end, masked in the kernel)."""
+    rng = np.random.default_rng(7)
+    cases = [(3840, 2160, 1280), (3840, 270, 1280), (7680, 4320, 1280), (1, 1, 1280), (64, 4, 1), (65, 17, 3), (100, 100, 1280)]
+    cases += [(int(rng.integers(1, 9000)), int(rng.integers(1, 5000)), int(rng.integers(1, 3000))) for _ in range(300)]
+    for w, rows, slots in cases:
+        p = capi.tile_plan(w, rows, slots)
+        assert p["strips"] == (w + 63) // 64
+        assert p["rows4"] % 16 == 0 and p["rows2"] % 8 == 0
+        assert p["tiles4"] == p["strips"] * (p["rows4"] // 16) and p["tiles2"] == p["strips"] * (p["rows2"] // 8)
+        rest = max(0, rows - p["rows4"] - p["rows2"])
+        assert p["tiles1"] == p["strips"] * ((rest + 3) // 4)
+        covered = p["rows4"] + p["rows2"] + 4 * (p["tiles1"] // p["strips"])
+        assert covered >= rows, (w, rows, slots, p)
+        # sections before the last used one must end inside the band, otherwise two sections would paint the same rows
+        if p["tiles1"]:
+            assert p["rows4"] + p["rows2"] < rows
+        if p["rows2"] and p["rows4"]:
+            assert p["rows4"] < rows
+        assert covered - rows < 16
+    big = capi.tile_plan(3840, 2160, 1280)
+    assert big["rows4"] == 1824 and big["rows2"] == 216 and big["tiles1"] == 60 * 30
+    band = capi.tile_plan(3840, 270, 1280)
+    assert band["rows4"] == 0 and band["tiles2"] == 60 * 34 and band["tiles1"] == 0
