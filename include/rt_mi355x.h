@@ -32,6 +32,7 @@ extern "C" {
 
 /* object kinds — object/mod.rs:7-10 (trait Object); only Sphere exists in the reference (object/sphere.rs) */
 #define RT_SPHERE 0u
+#define RT_PLANE 1u /* EXTENSION (no reference counterpart): two-sided plane, an `impl Object` in the shape of object/sphere.rs:19-45 */
 /* light kinds — light/mod.rs:8-10 (trait Light): light/point.rs, light/ambient.rs */
 #define RT_POINT 0u
 #define RT_AMBIENT 1u
@@ -50,9 +51,12 @@ extern "C" {
  */
 typedef struct rt_objects {
     int32_t n;
-    const uint8_t* kind; /* n entries, RT_SPHERE; NULL => all spheres */
-    const float *cx, *cy, *cz, *radius;
+    const uint8_t* kind; /* n entries, RT_SPHERE / RT_PLANE; NULL => all spheres */
+    const float *cx, *cy, *cz, *radius; /* RT_PLANE: (cx,cy,cz) = a point of the plane, radius ignored */
     const float *refl_r, *refl_g, *refl_b;
+    /* RT_PLANE only: unit normal.  is_hit_by(ray) = Some(t) iff t = dot3(point - origin, n) / dot3(direction, n) is finite and >= 0;
+       normal(at) = n.  Ignored for spheres; may be NULL when no element is a plane. */
+    const float *nx, *ny, *nz;
 } rt_objects;
 
 /* Flattened `&[DynLight]` (renderer.rs:38, light/point.rs:5-9, light/ambient.rs:5-7), list order preserved (renderer.rs:60-64). */

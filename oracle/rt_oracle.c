@@ -120,6 +120,22 @@ int rto_sphere_is_hit_by(const float o[3], const float d[3], const float c[3], f
     return sphere_is_hit_by((v3){o[0], o[1], o[2]}, (v3){d[0], d[1], d[2]}, (v3){c[0], c[1], c[2]}, r, t);
 }
 
+/* EXTENSION: plane primitive (semantics in rt_oracle.h), same operation discipline: one rounding per statement, dot3 order */
+static inline int plane_is_hit_by(v3 o, v3 d, v3 p0, v3 n, float* t)
+{
+    float denom = dot3(d, n);
+    float num = dot3(sub3(p0, o), n);
+    float x = num / denom;
+    if (isnan(x) || isinf(x)) return 0;
+    if (x < 0.0f) return 0;
+    *t = x;
+    return 1;
+}
+int rto_plane_is_hit_by(const float o[3], const float d[3], const float p0[3], const float n[3], float* t)
+{
+    return plane_is_hit_by((v3){o[0], o[1], o[2]}, (v3){d[0], d[1], d[2]}, (v3){p0[0], p0[1], p0[2]}, (v3){n[0], n[1], n[2]}, t);
+}
+
 /* light/point.rs:25-30 */
 static inline int point_hits(v3 lp, v3 lc, float intensity, v3 point, v3* out)
 {
@@ -158,6 +174,15 @@ typedef struct {
 } job_t;
 
 static inline v3 obj_center(const rto_objects* o, int k) { return (v3){o->cx[k], o->cy[k], o->cz[k]}; }
+static inline int obj_is_plane(const rto_objects* o, int k) { return o->kind && o->kind[k] == RTO_KIND_PLANE; }
+static inline v3 obj_plane_normal(const rto_objects* o, int k) { return (v3){o->nx[k], o->ny[k], o->nz[k]}; }
+
+/* Object::is_hit_by through the Box<dyn Object> of renderer.rs:48 (object/mod.rs:31-33) */
+static inline int object_is_hit_by(const rto_objects* objs, int k, v3 o, v3 d, float* t)
+{
+    if (obj_is_plane(objs, k)) return plane_is_hit_by(o, d, obj_center(objs, k), obj_plane_normal(objs, k), t);
+    return sphere_is_hit_by(o, d, obj_center(objs, k), objs->radius[k], t);
+}
 
 /* renderer.rs:47-54 — closest hit; strict `<` so the lowest index wins ties */
 static inline int closest_hit(const rto_objects* objs, v3 o, v3 d, float* t_out)
@@ -166,7 +191,7 @@ static inline int closest_hit(const rto_objects* objs, v3 o, v3 d, float* t_out)
     float best_t = 0.0f;
     for (int k = 0; k < objs->n; ++k) {
         float t;
-        if (!sphere_is_hit_by(o, d, obj_center(objs, k), objs->radius[k], &t)) continue;
+        if (!object_is_hit_by(objs, k, o, d, &t)) continue;
         if (best < 0 || t < best_t) { best = k; best_t = t; }
     }
     *t_out = best_t;
@@ -181,7 +206,7 @@ static inline int occluded(const rto_objects* objs, v3 p, v3 lp)
     v3 dir = (v3){to_l.x / dist, to_l.y / dist, to_l.z / dist};
     for (int k = 0; k < objs->n; ++k) {
         float t;
-        if (sphere_is_hit_by(p, dir, obj_center(objs, k), objs->radius[k], &t) && t > RTO_SHADOW_EPS && t < dist) return 1;
+        if (object_is_hit_by(objs, k, p, dir, &t) && t > RTO_SHADOW_EPS && t < dist) return 1;
     }
     return 0;
 }
@@ -221,7 +246,8 @@ static inline void render_pixel(const job_t* jb, uint32_t i, uint32_t j, uint8_t
         v3 refl = {objs->refl_r[k], objs->refl_g[k], objs->refl_b[k]};
         color = mul3(c, refl); /* :66 */
         if (it < limit) {      /* :67 */
-            v3 normal = unit3(sub3(o, obj_center(objs, k)));   /* :68 — normal at the OLD origin (reference quirk), sphere.rs:21-23 */
+            /* :68 — normal at the OLD origin (reference quirk): sphere.rs:21-23; a plane's normal is the same everywhere */
+            v3 normal = obj_is_plane(objs, k) ? obj_plane_normal(objs, k) : unit3(sub3(o, obj_center(objs, k)));
             float dn = dot3(d, normal);                        /* object/mod.rs:72 */
             float two_dn = 2.0f * dn;
             d = unit3(sub3(d, scale3(two_dn, normal)));        /* object/mod.rs:72 */
@@ -267,8 +293,10 @@ int rto_render(const rto_objects* objs, const rto_lights* lights, const float m[
 {
     if (!objs || !lights || !m || !out || depth == 0 || w == 0 || h == 0 || y0 > y1 || y1 > h || row_step == 0 || (channels != 3 && channels != 4) || objs->n < 0 || lights->n < 0)
         return -1;
-    for (int k = 0; k < objs->n; ++k)
-        if (objs->kind && objs->kind[k] != RTO_KIND_SPHERE) return -1;
+    for (int k = 0; k < objs->n; ++k) {
+        if (!objs->kind || objs->kind[k] == RTO_KIND_SPHERE) continue;
+        if (objs->kind[k] != RTO_KIND_PLANE || !objs->nx || !objs->ny || !objs->nz) return -1;
+    }
     job_t jb = {objs, lights, m, w, h, y0, y1, row_step, depth, flags, channels, out, hit_idx, 0};
     if (nthreads <= 0) nthreads = rto_default_threads();
     if (nthreads > 256) nthreads = 256;

@@ -10,8 +10,8 @@
  *   - tests/golden/result_100x100.rgb  = pixels of the reference's own result.png  (bit-exact, 10000/10000)
  *   - known-answer tests object/mod.rs:83-92, object/sphere.rs:47-57 (t == 4.0), math/mat4.rs:288-291
  * Unpinned by any reference artefact (source reading only): depth>1 bounce, Point::hits EPSILON cut,
- * Equal/Less branches of is_hit_by, saturation, non-square aspect. RTO_SHADOWS is an extension with no
- * counterpart in the reference.
+ * Equal/Less branches of is_hit_by, saturation, non-square aspect. RTO_SHADOWS and RTO_KIND_PLANE are extensions
+ * with no counterpart in the reference (their semantics are DEFINED here).
  */
 #ifndef RT_ORACLE_H
 #define RT_ORACLE_H
@@ -23,6 +23,7 @@ extern "C" {
 #endif
 
 #define RTO_KIND_SPHERE 0u
+#define RTO_KIND_PLANE 1u /* EXTENSION: the reference has one primitive (object/sphere.rs); see rto_plane_is_hit_by */
 #define RTO_LIGHT_POINT 0u
 #define RTO_LIGHT_AMBIENT 1u
 
@@ -36,6 +37,7 @@ typedef struct {
     const uint8_t* kind; /* NULL => all spheres */
     const float *cx, *cy, *cz, *radius;
     const float *refl_r, *refl_g, *refl_b;
+    const float *nx, *ny, *nz; /* RTO_KIND_PLANE: unit normal, (cx,cy,cz) = a point of the plane, radius unused; may be NULL without planes */
 } rto_objects;
 
 typedef struct {
@@ -58,6 +60,12 @@ float rto_dot3(const float a[3], const float b[3]);
 void rto_unit3(const float v[3], float out[3]);
 /* object/sphere.rs:26-44 — returns 1 and *t on Some(t), 0 on None */
 int rto_sphere_is_hit_by(const float origin[3], const float dir[3], const float center[3], float radius, float* t);
+/*
+ * EXTENSION (no reference counterpart; an `impl Object` in the shape of object/sphere.rs:19-45): two-sided plane through `point`
+ * with unit normal n.  is_hit_by: denom = dot3(d, n); num = dot3(point - origin, n); t = num / denom; Some(t) iff t is finite
+ * and t >= 0 (denom == 0, i.e. a parallel ray, gives inf or NaN => None).  normal(at) = n.  Returns 1 and *t on Some(t).
+ */
+int rto_plane_is_hit_by(const float origin[3], const float dir[3], const float point[3], const float n[3], float* t);
 /* light/point.rs:25-30 — returns 1 and out rgb on Some, 0 on None */
 int rto_point_hits(const float light_pos[3], const float light_color[3], float intensity, const float point[3], float out[3]);
 /* display.rs:98-100 — pixel (j = column, i = row) -> position (w dropped, vec3.rs:702-707) */

@@ -15,6 +15,7 @@ RT_ERR_NO_SCENE = -4
 RT_ERR_TOO_LARGE = -5
 
 RT_SPHERE = 0
+RT_PLANE = 1  # extension, no reference counterpart
 RT_POINT = 0
 RT_AMBIENT = 1
 
@@ -37,7 +38,7 @@ _u8p = C.POINTER(C.c_uint8)
 
 class RtObjects(C.Structure):
     _fields_ = [("n", C.c_int32), ("kind", _u8p), ("cx", _f32p), ("cy", _f32p), ("cz", _f32p), ("radius", _f32p),
-                ("refl_r", _f32p), ("refl_g", _f32p), ("refl_b", _f32p)]
+                ("refl_r", _f32p), ("refl_g", _f32p), ("refl_b", _f32p), ("nx", _f32p), ("ny", _f32p), ("nz", _f32p)]
 
 
 class RtLights(C.Structure):
@@ -104,7 +105,7 @@ def _ptr(a: Optional[np.ndarray], ty):
 class FlatObjects:
     """SoA view of `&[Element<DynObject>]` (element.rs:10-19, object/sphere.rs:6-9); keeps the numpy arrays alive."""
 
-    def __init__(self, cx, cy, cz, radius, refl_r, refl_g, refl_b, kind=None):
+    def __init__(self, cx, cy, cz, radius, refl_r, refl_g, refl_b, kind=None, nx=None, ny=None, nz=None):
         self.cx, self.cy, self.cz, self.radius = _f32(cx), _f32(cy), _f32(cz), _f32(radius)
         self.refl_r, self.refl_g, self.refl_b = _f32(refl_r), _f32(refl_g), _f32(refl_b)
         n = self.cx.size
@@ -112,11 +113,17 @@ class FlatObjects:
             if a.size != n:
                 raise ValueError("object arrays differ in length")
         self.kind = None if kind is None else np.ascontiguousarray(kind, dtype=np.uint8)
+        # RT_PLANE (extension): unit normals, read only for plane elements
+        self.nx, self.ny, self.nz = (None if a is None else _f32(a) for a in (nx, ny, nz))
+        for a in (self.nx, self.ny, self.nz):
+            if a is not None and a.size != n:
+                raise ValueError("normal arrays differ in length from the object arrays")
         self.n = n
 
     def c_struct(self) -> RtObjects:
         return RtObjects(self.n, _ptr(self.kind, _u8p), _ptr(self.cx, _f32p), _ptr(self.cy, _f32p), _ptr(self.cz, _f32p),
-                         _ptr(self.radius, _f32p), _ptr(self.refl_r, _f32p), _ptr(self.refl_g, _f32p), _ptr(self.refl_b, _f32p))
+                         _ptr(self.radius, _f32p), _ptr(self.refl_r, _f32p), _ptr(self.refl_g, _f32p), _ptr(self.refl_b, _f32p),
+                         _ptr(self.nx, _f32p), _ptr(self.ny, _f32p), _ptr(self.nz, _f32p))
 
 
 class FlatLights:

@@ -24,6 +24,10 @@ struct RenderArgs {
     const float4* lfilt;        // n_lights * n_pad: per-light shadow filter constants
     const int32_t* lalways;     // per-light always-test lists, concatenated
     const int32_t* lalways_off; // n_lights + 1
+    const float4* pln;          // n_pad: (nx, ny, nz, 1) for RT_PLANE elements (extension), 0 for spheres
+    const int32_t* planes;      // n_planes indices of the plane elements (tested exactly for every ray)
+    int32_t n_planes;
+    float ball[4];              // hit points farther than sqrt(ball[3]) from ball[0..2] bypass the per-light shadow filter
     uint8_t* out;           // band rows, 4 or 3 B/pixel
     int32_t* hit_idx;       // nullable
     // dense hit records (library-owned scratch, only for depth > 1 or RT_SHADOWS): one counter + capacity >= band pixels

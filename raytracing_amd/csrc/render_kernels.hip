@@ -86,6 +86,19 @@ __device__ __forceinline__ bool hit_general_exact(float ox, float oy, float oz, 
     return root_select(alpha, beta, t);
 }
 
+// EXTENSION (RT_PLANE, no reference counterpart; semantics = the oracle's plane_is_hit_by): p0 = a point of the plane, n = unit normal
+__device__ __forceinline__ bool hit_plane_exact(float ox, float oy, float oz, float dx, float dy, float dz, float4 p0, float4 n, float& t)
+{
+    const float denom = dot3_ref(dx, dy, dz, n.x, n.y, n.z);
+    const float qx = p0.x - ox, qy = p0.y - oy, qz = p0.z - oz;
+    const float num = dot3_ref(qx, qy, qz, n.x, n.y, n.z);
+    const float x = num / denom;
+    if (x != x || __builtin_isinf(x)) return false;  // parallel ray
+    if (x < 0.0f) return false;
+    t = x;
+    return true;
+}
+
 // renderer.rs:49-53 made order-independent: lexicographic minimum of (t, index)
 __device__ __forceinline__ void take_closest(bool hit, float t, int idx, float& best_t, int& best_i)
 {
@@ -181,6 +194,16 @@ __device__ __forceinline__ void trace_general(const RenderArgs& A, float* s_gen,
         best_i[p] = -1;
         best_t[p] = 0.0f;
     }
+    for (int a = 0; a < A.n_planes; ++a) {  // planes: no filter, exact test for every live ray
+        const int k = A.planes[a];
+        const float4 p0 = A.sph_r[k], n = A.pln[k];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            float t;
+            const bool h = hit_plane_exact(ox[p], oy[p], oz[p], ux[p], uy[p], uz[p], p0, n, t) && ((need >> p) & 1u);
+            take_closest(h, t, k, best_t[p], best_i[p]);
+        }
+    }
     for (int c0 = 0; c0 < A.n_pad; c0 += kChunk) {
         const int cn = min(kChunk, A.n_pad - c0);
         __syncthreads();
@@ -229,8 +252,10 @@ __device__ __forceinline__ void trace_general(const RenderArgs& A, float* s_gen,
 // light they share an origin, so the primary-ray 3-FMA filter applies with the per-light constants A.lfilt (scene_prep.cpp:
 // prepare_light_filters); candidates run the reference's exact general-origin test on the ORIGINAL ray (h, u), so the result is
 // bit-identical to the oracle's occluded().  Bit p of `occ` = ray p is blocked.  Contains workgroup barriers.
+// `far` marks rays whose hit point lies outside the ball the filter margins were derived for (only possible on planes): they skip
+// the filter and are tested exactly against every sphere.
 template <int P, int B, int CH>
-__device__ __forceinline__ void trace_shadow(const RenderArgs& A, float* s_buf, int tid, int l, uint32_t need, const float (&hx)[P], const float (&hy)[P],
+__device__ __forceinline__ void trace_shadow(const RenderArgs& A, float* s_buf, int tid, int l, uint32_t need, uint32_t far, const float (&hx)[P], const float (&hy)[P],
                                              const float (&hz)[P], const float (&ux)[P], const float (&uy)[P], const float (&uz)[P],
                                              const float (&sd)[P], uint32_t& occ)
 {
@@ -240,7 +265,7 @@ __device__ __forceinline__ void trace_shadow(const RenderArgs& A, float* s_buf, 
     float wx[P], wy[P], wz[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        const bool on = (need >> p) & 1u;  // dead rays: w = 0 => f = -1, never a candidate
+        const bool on = ((need & ~far) >> p) & 1u;  // dead (and far) rays: w = 0 => f = -1, never a candidate
         wx[p] = on ? -ux[p] : 0.0f;
         wy[p] = on ? -uy[p] : 0.0f;
         wz[p] = on ? -uz[p] : 0.0f;
@@ -258,7 +283,24 @@ __device__ __forceinline__ void trace_shadow(const RenderArgs& A, float* s_buf, 
             }
         }
     };
-    for (int a = A.lalways_off[l]; a < A.lalways_off[l + 1]; ++a) exact(A.lalways[a]);
+    for (int a = 0; a < A.n_planes; ++a) {  // planes: exact test for every ray
+        const int k = A.planes[a];
+        const float4 p0 = A.sph_r[k], n = A.pln[k];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            float t;
+            const bool h = hit_plane_exact(hx[p], hy[p], hz[p], ux[p], uy[p], uz[p], p0, n, t);
+            if (h && t > RT_SHADOW_EPS && t < sd[p] && ((need >> p) & 1u)) {
+                occ |= 1u << p;
+                wx[p] = wy[p] = wz[p] = 0.0f;
+            }
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64((need & far) != 0u) != 0ull) {  // rare: hit points beyond the filter's ball, every sphere exactly
+        for (int k = 0; k < A.n; ++k) exact(k);                     // (planes and padding entries carry a NaN radius: they miss)
+    } else {
+        for (int a = A.lalways_off[l]; a < A.lalways_off[l + 1]; ++a) exact(A.lalways[a]);
+    }
     uint32_t open = need & ~occ;
     const float4* const filt = A.lfilt + (size_t)l * A.n_pad;
     for (int c0 = 0; c0 < A.n_pad; c0 += CH) {
@@ -368,6 +410,18 @@ __device__ __forceinline__ void render_tile(const RenderArgs& A, float* s_x, flo
         for (int p = 0; p < P; ++p) {
             float t;
             bool h = hit_primary_exact(dx[p], dy[p], dz[p], s, t);
+            take_closest(h, t, k, best_t[p], best_i[p]);
+        }
+    }
+
+    // ---- planes (extension): no filter, exact test for every pixel ----
+    for (int a = 0; a < A.n_planes; ++a) {
+        const int k = A.planes[a];
+        const float4 p0 = A.sph_r[k], n = A.pln[k];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            float t;
+            bool h = hit_plane_exact(0.0f, 0.0f, 0.0f, dx[p], dy[p], dz[p], p0, n, t);
             take_closest(h, t, k, best_t[p], best_i[p]);
         }
     }
@@ -578,7 +632,7 @@ __global__ __launch_bounds__(kWaves * 64) void shadow_mask_kernel(const RenderAr
         if (A.lcol[l].w != 0.0f) continue;  // ambient lights are never shadowed (uniform over the workgroup)
         const uint32_t first = (t % groups) * per_group + (uint32_t)wave * (64 * P);
         float hx[P], hy[P], hz[P], sx[P], sy[P], sz[P], sd[P];
-        uint32_t need = 0u;
+        uint32_t need = 0u, far = 0u;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             const uint32_t r = first + p * 64 + lane;
@@ -592,6 +646,10 @@ __global__ __launch_bounds__(kWaves * 64) void shadow_mask_kernel(const RenderAr
             hx[p] = ox + tt * dx;  // renderer.rs:57
             hy[p] = oy + tt * dy;
             hz[p] = oz + tt * dz;
+            {  // inside the ball the per-light filter margins assume?  (NaN compares false => far)
+                const float bx = hx[p] - A.ball[0], by = hy[p] - A.ball[1], bz = hz[p] - A.ball[2];
+                if (!(bx * bx + by * by + bz * bz <= A.ball[3])) far |= 1u << p;
+            }
             {  // light/point.rs:25-30: a light whose contribution is cut off casts no shadow ray
                 const float vx = hx[p] - lp.x, vy = hy[p] - lp.y, vz = hz[p] - lp.z;
                 const float dist = sqrtf(dot3_ref(vx, vy, vz, vx, vy, vz));
@@ -605,7 +663,7 @@ __global__ __launch_bounds__(kWaves * 64) void shadow_mask_kernel(const RenderAr
             sz[p] = vz / sd[p];
         }
         uint32_t occ;
-        trace_shadow<P, B, CH>(A, s_buf, tid, l, need, hx, hy, hz, sx, sy, sz, sd, occ);
+        trace_shadow<P, B, CH>(A, s_buf, tid, l, need, A.n_planes ? far : 0u, hx, hy, hz, sx, sy, sz, sd, occ);
 #pragma unroll
         for (int p = 0; p < P; ++p)
             if ((occ >> p) & 1u) atomicOr(A.rec_occ + (size_t)(l >> 5) * A.rec_cap + (first + p * 64 + lane), 1u << (l & 31));
@@ -712,6 +770,10 @@ __global__ __launch_bounds__(kWaves * 64) void shade_iter_kernel(const RenderArg
         const float4 s = A.sph_r[on ? best_i[p] : 0];
         float nx = ox[p] - s.x, ny = oy[p] - s.y, nz = oz[p] - s.z;  // renderer.rs:68 — normal at the OLD origin
         unit3(nx, ny, nz);
+        if (A.n_planes) {  // a plane's normal is the same everywhere (extension)
+            const float4 pn = A.pln[on ? best_i[p] : 0];
+            if (pn.w != 0.0f) { nx = pn.x; ny = pn.y; nz = pn.z; }
+        }
         const float dn = dot3_ref(dx[p], dy[p], dz[p], nx, ny, nz);  // object/mod.rs:72
         const float two_dn = 2.0f * dn;
         float ex = dx[p] - two_dn * nx, ey = dy[p] - two_dn * ny, ez = dz[p] - two_dn * nz;

@@ -30,6 +30,10 @@ struct rt_ctx {
     const int32_t* d_always = nullptr;
     const float4* d_lfilt = nullptr;
     const int32_t *d_lalways = nullptr, *d_lalways_off = nullptr;
+    const float4* d_pln = nullptr;
+    const int32_t* d_planes = nullptr;
+    int32_t n_planes = 0;
+    float ball[4] = {0, 0, 0, 0};
     // staging for the host-output entry points
     void* d_out = nullptr;
     size_t d_out_bytes = 0;
@@ -176,7 +180,10 @@ int32_t rt_scene_upload(rt_ctx* c, const rt_objects* o, const rt_lights* l)
     const size_t nla = ps.lalways.size();
     const size_t off_lalw = off_lfilt + (nl ? nl : 1) * np * 16;
     const size_t off_laoff = off_lalw + ((nla ? nla : 1) * 4 + 15) / 16 * 16;
-    const size_t total = off_laoff + ((nl + 1) * 4 + 15) / 16 * 16;
+    const size_t off_pln = off_laoff + ((nl + 1) * 4 + 15) / 16 * 16;
+    const size_t npl = ps.planes.size();
+    const size_t off_planes = off_pln + np * 16;
+    const size_t total = off_planes + ((npl ? npl : 1) * 4 + 15) / 16 * 16;
     std::vector<unsigned char> host(total, 0);
     std::memcpy(host.data() + off_filt, ps.filt.data(), np * 16);
     std::memcpy(host.data() + off_sph, ps.sph.data(), np * 16);
@@ -189,6 +196,8 @@ int32_t rt_scene_upload(rt_ctx* c, const rt_objects* o, const rt_lights* l)
     if (nl) std::memcpy(host.data() + off_lfilt, ps.lfilt.data(), nl * np * 16);
     if (nla) std::memcpy(host.data() + off_lalw, ps.lalways.data(), nla * 4);
     std::memcpy(host.data() + off_laoff, ps.lalways_off.data(), (nl + 1) * 4);
+    std::memcpy(host.data() + off_pln, ps.pln.data(), np * 16);
+    if (npl) std::memcpy(host.data() + off_planes, ps.planes.data(), npl * 4);
 
     RT_HIP(c, hipStreamSynchronize(c->stream));  // no render may still read the old scene
     if (total > c->scene_bytes) {
@@ -213,6 +222,10 @@ int32_t rt_scene_upload(rt_ctx* c, const rt_objects* o, const rt_lights* l)
     c->d_lfilt = reinterpret_cast<const float4*>(base + off_lfilt);
     c->d_lalways = reinterpret_cast<const int32_t*>(base + off_lalw);
     c->d_lalways_off = reinterpret_cast<const int32_t*>(base + off_laoff);
+    c->d_pln = reinterpret_cast<const float4*>(base + off_pln);
+    c->d_planes = reinterpret_cast<const int32_t*>(base + off_planes);
+    c->n_planes = (int32_t)npl;
+    std::memcpy(c->ball, ps.ball, sizeof(c->ball));
     c->n = ps.n;
     c->n_pad = ps.n_pad;
     c->n_always = (int32_t)na;
@@ -244,7 +257,7 @@ static int32_t enqueue_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h
     std::memcpy(a.m, m, sizeof(a.m));
     a.w = w; a.h = h; a.y0 = y0; a.y1 = y1; a.depth = depth; a.flags = flags;
     a.n = c->n; a.n_pad = c->n_pad; a.n_always = c->n_always; a.n_lights = c->n_lights;
-    a.filt = c->d_filt; a.sph = c->d_sph; a.sph_r = c->d_sph_r; a.gen = c->d_gen; a.refl = c->d_refl; a.always = c->d_always; a.lpos = c->d_lpos; a.lcol = c->d_lcol; a.lfilt = c->d_lfilt; a.lalways = c->d_lalways; a.lalways_off = c->d_lalways_off;
+    a.filt = c->d_filt; a.sph = c->d_sph; a.sph_r = c->d_sph_r; a.gen = c->d_gen; a.refl = c->d_refl; a.always = c->d_always; a.lpos = c->d_lpos; a.lcol = c->d_lcol; a.lfilt = c->d_lfilt; a.lalways = c->d_lalways; a.lalways_off = c->d_lalways_off; a.pln = c->d_pln; a.planes = c->d_planes; a.n_planes = c->n_planes; std::memcpy(a.ball, c->ball, sizeof(a.ball));
     a.out = static_cast<uint8_t*>(d_out);
     a.hit_idx = static_cast<int32_t*>(d_hit_idx);
     a.rec_count = nullptr; a.rec_pix = nullptr; a.rec_idx = nullptr; a.rec_t = nullptr;

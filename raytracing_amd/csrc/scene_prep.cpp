@@ -81,8 +81,10 @@ static void prepare_light_filters(const rt_objects* o, const rt_lights* l, Prepa
         }
     };
     std::vector<char> fin(n, 0);
+    auto is_plane = [&](int32_t i) { return o->kind && o->kind[i] == RT_PLANE; };
     for (int32_t i = 0; i < n; ++i) {
-        fin[i] = std::isfinite(o->cx[i]) && std::isfinite(o->cy[i]) && std::isfinite(o->cz[i]) && std::isfinite(o->radius[i]);
+        // planes are unbounded: they do not shape the ball; their far hit points are handled exactly by the kernel (out.ball)
+        fin[i] = !is_plane(i) && std::isfinite(o->cx[i]) && std::isfinite(o->cy[i]) && std::isfinite(o->cz[i]) && std::isfinite(o->radius[i]);
         if (fin[i]) grow(o->cx[i], o->cy[i], o->cz[i]);
     }
     const double C[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
@@ -90,6 +92,9 @@ static void prepare_light_filters(const rt_objects* o, const rt_lights* l, Prepa
     double Rs = distC(0, 0, 0);
     for (int32_t i = 0; i < n; ++i)
         if (fin[i]) Rs = std::fmax(Rs, distC(o->cx[i], o->cy[i], o->cz[i]) + std::fabs((double)o->radius[i]));
+    // hit points within 0.999 Rs of C (in f32 arithmetic) are certainly inside the ball the margins below assume
+    out.ball[0] = (float)C[0]; out.ball[1] = (float)C[1]; out.ball[2] = (float)C[2];
+    out.ball[3] = (float)(0.998 * Rs * Rs);
     for (int32_t m = 0; m < nl; ++m) {
         const uint8_t kind = l->kind ? l->kind[m] : (uint8_t)RT_POINT;
         out.lalways_off[m] = (int32_t)out.lalways.size();
@@ -98,6 +103,7 @@ static void prepare_light_filters(const rt_objects* o, const rt_lights* l, Prepa
         const bool lfin = std::isfinite(lx) && std::isfinite(ly) && std::isfinite(lz);
         const double Sl = lfin ? distC(lx, ly, lz) + Rs : 0.0;  // >= every |lp - h|
         for (int32_t i = 0; i < n; ++i) {
+            if (is_plane(i)) continue;  // lfilt stays 0 (never a candidate); planes are tested exactly through out.planes
             bool ok = fin[i] && lfin;
             double qx = 0, qy = 0, qz = 0, s = 1, M = 0;
             if (ok) {
@@ -131,8 +137,11 @@ std::string prepare_scene(const rt_objects* o, const rt_lights* l, PreparedScene
     if (o->n < 0 || l->n < 0) return "negative count";
     if (o->n > 0 && (!o->cx || !o->cy || !o->cz || !o->radius || !o->refl_r || !o->refl_g || !o->refl_b)) return "objects: null array";
     if (l->n > 0 && (!l->cr || !l->cg || !l->cb)) return "lights: null colour array";
-    for (int32_t i = 0; i < o->n; ++i)
-        if (o->kind && o->kind[i] != RT_SPHERE) return "objects: unknown kind (only RT_SPHERE exists, object/sphere.rs)";
+    for (int32_t i = 0; i < o->n; ++i) {
+        if (!o->kind || o->kind[i] == RT_SPHERE) continue;
+        if (o->kind[i] != RT_PLANE) return "objects: unknown kind (RT_SPHERE = object/sphere.rs, RT_PLANE = extension)";
+        if (!o->nx || !o->ny || !o->nz) return "objects: null normal array for a plane";
+    }
     for (int32_t i = 0; i < l->n; ++i) {
         uint8_t k = l->kind ? l->kind[i] : (uint8_t)RT_POINT;
         if (k != RT_POINT && k != RT_AMBIENT) return "lights: unknown kind";
@@ -150,10 +159,22 @@ std::string prepare_scene(const rt_objects* o, const rt_lights* l, PreparedScene
     out.sph_r.assign(out.n_pad, f4{0, 0, 0, NAN});
     out.gen.assign(out.n_pad, f4{0, 0, 0, inf});  // -rho = +inf: W = +inf, g = -inf, never a candidate
     out.refl.assign(out.n_pad, f4{0, 0, 0, 0});
+    out.pln.assign(out.n_pad, f4{0, 0, 0, 0});
     out.cls.assign(o->n, 0);
     std::vector<float> k(o->n);
     prepare_filter(o->n, o->cx, o->cy, o->cz, o->radius, out.filt.data(), out.cls.data(), k.data());
     for (int32_t i = 0; i < o->n; ++i) {
+        if (o->kind && o->kind[i] == RT_PLANE) {
+            // a plane never passes a sphere filter and never passes a sphere test (k = +inf, radius NaN, -rho = +inf: see the padding)
+            out.filt[i] = f4{0, 0, 0, 0};
+            out.cls[i] = 2;
+            out.sph[i] = f4{o->cx[i], o->cy[i], o->cz[i], inf};
+            out.sph_r[i] = f4{o->cx[i], o->cy[i], o->cz[i], NAN};
+            out.pln[i] = f4{o->nx[i], o->ny[i], o->nz[i], 1.0f};
+            out.refl[i] = f4{o->refl_r[i], o->refl_g[i], o->refl_b[i], 0.0f};
+            out.planes.push_back(i);
+            continue;
+        }
         out.sph[i] = f4{o->cx[i], o->cy[i], o->cz[i], k[i]};
         out.sph_r[i] = f4{o->cx[i], o->cy[i], o->cz[i], o->radius[i]};
         {

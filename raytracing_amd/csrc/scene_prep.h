@@ -25,7 +25,11 @@ struct PreparedScene {
     std::vector<f4> gen;         // n_pad: (cx, cy, cz, -rho), rho = r*r (1+eta)/(1-eta) rounded up: general-origin filter
     std::vector<f4> refl;        // n_pad: Material.reflectiveness (element.rs:18), w unused
     std::vector<int32_t> always; // indices of spheres the filter cannot cover (origin inside / on / absurd values): tested exactly for every pixel
-    std::vector<uint8_t> cls;    // n: 1 = filterable, 0 = always
+    std::vector<uint8_t> cls;    // n: 1 = filterable sphere, 0 = sphere always tested exactly, 2 = plane
+    std::vector<f4> pln;         // n_pad: (nx, ny, nz, 1) for RT_PLANE elements, 0 otherwise
+    std::vector<int32_t> planes; // indices of the RT_PLANE elements: tested exactly for every ray (no filter)
+    float ball[4] = {0, 0, 0, 0}; // centre and squared radius of the ball the shadow filters were derived for (hit points outside it
+                                  // — possible only on planes — take the exact path)
     std::vector<f4> lpos;        // n_lights: (px, py, pz, intensity)
     std::vector<f4> lcol;        // n_lights: (cr, cg, cb, kind as float: 0 = point, 1 = ambient)
     // RT_SHADOWS: per light the shadow rays share the end point lp, so seen from the light they are "primary rays" and the

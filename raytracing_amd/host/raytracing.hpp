@@ -13,6 +13,7 @@
 // Nothing here computes a pixel: the per-pixel path lives in the HIP kernels.  There is no CPU fallback.
 #pragma once
 
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -45,6 +46,7 @@ inline Vec3 operator*(float s, Vec3 v) { return Vec3(s * v.x, s * v.y, s * v.z);
 struct FlatObject {
     uint8_t kind;
     float cx, cy, cz, radius;
+    float nx = 0.0f, ny = 0.0f, nz = 0.0f;  // RT_PLANE only: unit normal
 };
 struct FlatLight {
     uint8_t kind;
@@ -66,7 +68,26 @@ struct Sphere final : Object {
     Sphere(Vec3 c, float r) : center(c), radius(r) {}
     bool flatten(FlatObject& f) const override
     {
-        f = FlatObject{(uint8_t)RT_SPHERE, center.x, center.y, center.z, radius};
+        f = FlatObject{(uint8_t)RT_SPHERE, center.x, center.y, center.z, radius, 0.0f, 0.0f, 0.0f};
+        return true;
+    }
+};
+
+// EXTENSION (no reference counterpart): two-sided infinite plane, an `impl Object` in the shape of object/sphere.rs:19-45.
+// The normal is normalised once here like vec3.rs:195-197 (v / sqrt((xx + yy) + (zz + 0)), true divisions).
+struct Plane final : Object {
+    Vec3 point, normal;
+    Plane() = default;
+    Plane(Vec3 p, Vec3 n) : point(p)
+    {
+        const float xx = n.x * n.x, yy = n.y * n.y, zz = n.z * n.z;
+        const float lo = xx + yy, hi = zz + 0.0f;
+        const float len = std::sqrt(lo + hi);
+        normal = Vec3(n.x / len, n.y / len, n.z / len);
+    }
+    bool flatten(FlatObject& f) const override
+    {
+        f = FlatObject{(uint8_t)RT_PLANE, point.x, point.y, point.z, 0.0f, normal.x, normal.y, normal.z};
         return true;
     }
 };
@@ -268,7 +289,7 @@ private:
     {
         const size_t n = elements.size(), nl = lights.size();
         std::vector<uint8_t> kind(n), lkind(nl);
-        std::vector<float> a[7], b[7];
+        std::vector<float> a[10], b[7];
         for (auto& v : a) v.resize(n);
         for (auto& v : b) v.resize(nl);
         for (size_t i = 0; i < n; ++i) {
@@ -278,6 +299,7 @@ private:
             a[0][i] = f.cx; a[1][i] = f.cy; a[2][i] = f.cz; a[3][i] = f.radius;
             const Vec3 r = elements[i].material.reflectiveness;
             a[4][i] = r.x; a[5][i] = r.y; a[6][i] = r.z;
+            a[7][i] = f.nx; a[8][i] = f.ny; a[9][i] = f.nz;
         }
         for (size_t i = 0; i < nl; ++i) {
             FlatLight f;
@@ -285,7 +307,8 @@ private:
             lkind[i] = f.kind;
             b[0][i] = f.px; b[1][i] = f.py; b[2][i] = f.pz; b[3][i] = f.cr; b[4][i] = f.cg; b[5][i] = f.cb; b[6][i] = f.intensity;
         }
-        rt_objects o{(int32_t)n, kind.data(), a[0].data(), a[1].data(), a[2].data(), a[3].data(), a[4].data(), a[5].data(), a[6].data()};
+        rt_objects o{(int32_t)n, kind.data(), a[0].data(), a[1].data(), a[2].data(), a[3].data(), a[4].data(), a[5].data(), a[6].data(),
+                     a[7].data(), a[8].data(), a[9].data()};
         rt_lights l{(int32_t)nl, lkind.data(), b[0].data(), b[1].data(), b[2].data(), b[3].data(), b[4].data(), b[5].data(), b[6].data()};
         check(rt_scene_upload(ctx_, &o, &l), ctx_);
     }

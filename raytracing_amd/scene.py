@@ -49,6 +49,24 @@ class Sphere:
 
 
 @dataclass(frozen=True)
+class Plane:
+    """EXTENSION (no reference counterpart): a two-sided infinite plane through `point` with normal `normal`, an `impl Object`
+    in the shape of object/sphere.rs:19-45.  The normal is normalised once here in f32 (the role `UnitVec3` plays in the reference:
+    Object::normal returns a UnitVec3, object/mod.rs:8): v / sqrt((xx + yy) + (zz + 0)) with true divisions, vec3.rs:195-197."""
+    point: Vec3
+    normal: Vec3
+
+    def unit_normal(self):
+        f = np.float32
+        x, y, z = f(self.normal.x), f(self.normal.y), f(self.normal.z)
+        n = np.sqrt(f(f(x * x) + f(y * y)) + f(f(z * z) + f(0.0)), dtype=f)
+        return float(x / n), float(y / n), float(z / n)
+
+    def flatten(self):
+        return (capi.RT_PLANE, self.point.x, self.point.y, self.point.z, 0.0)
+
+
+@dataclass(frozen=True)
 class Material:
     """element.rs:15-19 — only `reflectiveness` is read by the renderer (renderer.rs:66)."""
     color: Vec3
@@ -58,7 +76,7 @@ class Material:
 @dataclass(frozen=True)
 class Element:
     """element.rs:10-13"""
-    object: Sphere
+    object: object  # Sphere (reference) or Plane (extension)
     material: Material
 
     @staticmethod
@@ -91,16 +109,21 @@ class Ambient:
 
 
 def flatten_elements(elements: Sequence[Element]) -> capi.FlatObjects:
-    rows = []
+    rows, kinds = [], []
     for e in elements:
         fl = getattr(e.object, "flatten", None)
         if fl is None:
-            raise TypeError(f"object {type(e.object).__name__} cannot be flattened (only Sphere exists in the reference)")
-        _, cx, cy, cz, r = fl()
+            raise TypeError(f"object {type(e.object).__name__} cannot be flattened (Sphere is the reference's primitive, Plane the extension)")
+        kind, cx, cy, cz, r = fl()
         rf = e.material.reflectiveness
-        rows.append((cx, cy, cz, r, rf.x, rf.y, rf.z))
-    a = np.asarray(rows, dtype=np.float32).reshape(-1, 7)
-    return capi.FlatObjects(a[:, 0], a[:, 1], a[:, 2], a[:, 3], a[:, 4], a[:, 5], a[:, 6])
+        nx, ny, nz = e.object.unit_normal() if kind == capi.RT_PLANE else (0.0, 0.0, 0.0)
+        rows.append((cx, cy, cz, r, rf.x, rf.y, rf.z, nx, ny, nz))
+        kinds.append(kind)
+    a = np.asarray(rows, dtype=np.float32).reshape(-1, 10)
+    if not any(k == capi.RT_PLANE for k in kinds):  # the reference's case: spheres only, no kind / normal arrays needed
+        return capi.FlatObjects(a[:, 0], a[:, 1], a[:, 2], a[:, 3], a[:, 4], a[:, 5], a[:, 6])
+    return capi.FlatObjects(a[:, 0], a[:, 1], a[:, 2], a[:, 3], a[:, 4], a[:, 5], a[:, 6], kind=np.asarray(kinds, dtype=np.uint8),
+                            nx=a[:, 7], ny=a[:, 8], nz=a[:, 9])
 
 
 def flatten_lights(lights: Sequence) -> capi.FlatLights:

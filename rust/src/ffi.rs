@@ -4,6 +4,7 @@ use std::os::raw::{c_char, c_void};
 
 pub const RT_OK: i32 = 0;
 pub const RT_SPHERE: u8 = 0;
+pub const RT_PLANE: u8 = 1; // extension, no counterpart in the reference
 pub const RT_POINT: u8 = 0;
 pub const RT_AMBIENT: u8 = 1;
 pub const RT_SHADOWS: u32 = 1;
@@ -20,6 +21,10 @@ pub struct rt_objects {
     pub refl_r: *const f32,
     pub refl_g: *const f32,
     pub refl_b: *const f32,
+    /// RT_PLANE only (extension): unit normal; may be null when no element is a plane
+    pub nx: *const f32,
+    pub ny: *const f32,
+    pub nz: *const f32,
 }
 
 #[repr(C)]

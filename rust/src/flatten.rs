@@ -9,6 +9,8 @@ pub struct FlatObject {
     pub kind: u8,
     pub center: [f32; 3],
     pub radius: f32,
+    /// RT_PLANE only (extension): unit normal; [0.0; 3] for spheres
+    pub normal: [f32; 3],
 }
 
 #[derive(Debug, Clone, Copy, PartialEq)]
@@ -27,7 +29,7 @@ pub struct FlatLight {
 // --- object/sphere.rs: add to `impl Object for Sphere` -------------------------------------------------
 //     #[inline]
 //     fn flatten(&self) -> Option<FlatObject> {
-//         Some(FlatObject { kind: RT_SPHERE, center: self.center.to_array(), radius: self.radius })
+//         Some(FlatObject { kind: RT_SPHERE, center: self.center.to_array(), radius: self.radius, normal: [0.0; 3] })
 //     }
 
 // --- light/mod.rs: add to `pub trait Light` (+ blanket impls) ------------------------------------------
@@ -51,6 +53,7 @@ pub struct FlatScene {
     pub okind: Vec<u8>,
     pub cx: Vec<f32>, pub cy: Vec<f32>, pub cz: Vec<f32>, pub radius: Vec<f32>,
     pub refl_r: Vec<f32>, pub refl_g: Vec<f32>, pub refl_b: Vec<f32>,
+    pub nx: Vec<f32>, pub ny: Vec<f32>, pub nz: Vec<f32>,
     pub lkind: Vec<u8>,
     pub px: Vec<f32>, pub py: Vec<f32>, pub pz: Vec<f32>,
     pub cr: Vec<f32>, pub cg: Vec<f32>, pub cb: Vec<f32>, pub intensity: Vec<f32>,
@@ -61,6 +64,7 @@ impl FlatScene {
         self.okind.push(o.kind);
         self.cx.push(o.center[0]); self.cy.push(o.center[1]); self.cz.push(o.center[2]); self.radius.push(o.radius);
         self.refl_r.push(reflectiveness[0]); self.refl_g.push(reflectiveness[1]); self.refl_b.push(reflectiveness[2]);
+        self.nx.push(o.normal[0]); self.ny.push(o.normal[1]); self.nz.push(o.normal[2]);
     }
     pub fn push_light(&mut self, l: FlatLight) {
         self.lkind.push(l.kind);

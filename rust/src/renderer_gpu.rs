@@ -39,7 +39,8 @@ fn check(rc: i32, ctx: *const rt_ctx) -> anyhow::Result<()> {
 //     let mut ctx: *mut rt_ctx = std::ptr::null_mut();
 //     check(unsafe { rt_ctx_create(&mut ctx, 0) }, std::ptr::null())?;
 //     let objects = rt_objects { n: s.cx.len() as i32, kind: s.okind.as_ptr(), cx: s.cx.as_ptr(), cy: s.cy.as_ptr(), cz: s.cz.as_ptr(),
-//                                radius: s.radius.as_ptr(), refl_r: s.refl_r.as_ptr(), refl_g: s.refl_g.as_ptr(), refl_b: s.refl_b.as_ptr() };
+//                                radius: s.radius.as_ptr(), refl_r: s.refl_r.as_ptr(), refl_g: s.refl_g.as_ptr(), refl_b: s.refl_b.as_ptr(),
+//                                nx: s.nx.as_ptr(), ny: s.ny.as_ptr(), nz: s.nz.as_ptr() };
 //     let lts = rt_lights { n: s.cr.len() as i32, kind: s.lkind.as_ptr(), px: s.px.as_ptr(), py: s.py.as_ptr(), pz: s.pz.as_ptr(),
 //                           cr: s.cr.as_ptr(), cg: s.cg.as_ptr(), cb: s.cb.as_ptr(), intensity: s.intensity.as_ptr() };
 //     let res = (|| {

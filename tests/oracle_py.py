@@ -19,7 +19,7 @@ FLAG_SHADOWS = 1
 
 class RtoObjects(C.Structure):
     _fields_ = [("n", C.c_int32), ("kind", _u8p), ("cx", _f32p), ("cy", _f32p), ("cz", _f32p), ("radius", _f32p),
-                ("refl_r", _f32p), ("refl_g", _f32p), ("refl_b", _f32p)]
+                ("refl_r", _f32p), ("refl_g", _f32p), ("refl_b", _f32p), ("nx", _f32p), ("ny", _f32p), ("nz", _f32p)]
 
 
 class RtoLights(C.Structure):
@@ -42,6 +42,8 @@ class Oracle:
         lib.rto_unit3.argtypes = [_f32p, _f32p]
         lib.rto_sphere_is_hit_by.argtypes = [_f32p, _f32p, _f32p, C.c_float, _f32p]
         lib.rto_sphere_is_hit_by.restype = C.c_int
+        lib.rto_plane_is_hit_by.argtypes = [_f32p, _f32p, _f32p, _f32p, _f32p]
+        lib.rto_plane_is_hit_by.restype = C.c_int
         lib.rto_point_hits.argtypes = [_f32p, _f32p, C.c_float, _f32p, _f32p]
         lib.rto_point_hits.restype = C.c_int
         lib.rto_pixel_position.argtypes = [_f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _f32p]
@@ -82,6 +84,12 @@ class Oracle:
         hit = self.lib.rto_sphere_is_hit_by(o.ctypes.data_as(_f32p), d.ctypes.data_as(_f32p), c.ctypes.data_as(_f32p), radius, C.byref(t))
         return np.float32(t.value) if hit else None
 
+    def plane_is_hit_by(self, origin, direction, point, normal):
+        o, d, p, n = self._v(origin), self._v(direction), self._v(point), self._v(normal)
+        t = C.c_float()
+        hit = self.lib.rto_plane_is_hit_by(o.ctypes.data_as(_f32p), d.ctypes.data_as(_f32p), p.ctypes.data_as(_f32p), n.ctypes.data_as(_f32p), C.byref(t))
+        return np.float32(t.value) if hit else None
+
     def point_hits(self, lp, lc, intensity, p):
         lp, lc, p, o = self._v(lp), self._v(lc), self._v(p), np.zeros(3, np.float32)
         r = self.lib.rto_point_hits(lp.ctypes.data_as(_f32p), lc.ctypes.data_as(_f32p), intensity, p.ctypes.data_as(_f32p), o.ctypes.data_as(_f32p))
@@ -100,7 +108,8 @@ class Oracle:
         y1 = h if y1 is None else y1
         m = self._v(m)
         o = RtoObjects(objs.n, _p(objs.kind, _u8p), _p(objs.cx, _f32p), _p(objs.cy, _f32p), _p(objs.cz, _f32p), _p(objs.radius, _f32p),
-                       _p(objs.refl_r, _f32p), _p(objs.refl_g, _f32p), _p(objs.refl_b, _f32p))
+                       _p(objs.refl_r, _f32p), _p(objs.refl_g, _f32p), _p(objs.refl_b, _f32p),
+                       _p(getattr(objs, "nx", None), _f32p), _p(getattr(objs, "ny", None), _f32p), _p(getattr(objs, "nz", None), _f32p))
         l = RtoLights(lights.n, _p(lights.kind, _u8p), _p(lights.px, _f32p), _p(lights.py, _f32p), _p(lights.pz, _f32p),
                       _p(lights.cr, _f32p), _p(lights.cg, _f32p), _p(lights.cb, _f32p), _p(lights.intensity, _f32p))
         out = np.zeros((y1 - y0, w, channels), np.uint8)

@@ -140,3 +140,33 @@ def test_oracle_bands_and_threads_agree(oracle):
     # row_step leaves skipped rows untouched (zero)
     strided = oracle.render(objs, lights, m, 64, 48, row_step=4)
     assert np.array_equal(strided[::4], full[::4]) and not strided[1::4].any()
+
+
+def test_plane_extension_known_answers(oracle):
+    """RT_PLANE has no reference counterpart: these values pin the semantics DEFINED in oracle/rt_oracle.h (computed by hand)."""
+    f = np.float32
+    hit = oracle.plane_is_hit_by
+    assert hit([0, 0, 0], [0, 0, -1], [0, 0, -5], [0, 0, 1]) == f(5.0)       # head-on, from the front
+    assert hit([0, 0, 0], [0, 0, -1], [3, -2, -5], [0, 0, -1]) == f(5.0)     # two-sided, any point of the plane
+    assert hit([0, 0, 0], [1, 0, 0], [0, 0, -5], [0, 0, 1]) is None          # parallel: -5 / 0 = -inf
+    assert hit([0, 0, -5], [1, 0, 0], [0, 0, -5], [0, 0, 1]) is None         # in the plane: 0 / 0 = NaN
+    assert hit([0, 0, 0], [0, 0, 1], [0, 0, -5], [0, 0, 1]) is None          # behind the ray
+    t = hit([0, 0, -5], [0, 0, -1], [0, 0, -5], [0, 0, 1])                   # origin on the plane: 0 / -1 = -0.0, not < 0 => Some
+    assert t is not None and t == f(0.0)
+    t = hit([0, 1, 0], [0.6, -0.8, 0], [0, -1, 0], [0, 1, 0])                # oblique: num = -2, denom = -0.8 (f32)
+    assert t == f(-2.0) / f(-0.8)
+    # end to end: a plane facing the camera at z = -5, point light at the origin, centre pixel of an even-width frame looks down -z
+    from raytracing_amd import capi
+    objs = capi.FlatObjects([0], [0], [-5], [0], [1.0], [0.5], [0.25], kind=np.array([1], np.uint8), nx=[0], ny=[0], nz=[1])
+    lights = capi.FlatLights([0], [0], [0], [1], [1], [1], [0.5])
+    m = oracle.default_camera(64, 64)
+    img, hitidx = oracle.render(objs, lights, m, 64, 64, want_hit_idx=True)
+    assert (hitidx == 0).all()  # an infinite plane in front of the camera fills the frame
+    # t = 5, p = (0,0,-5), dist = 5, I' = 0.5 / 25 = 0.02; bytes = trunc(255 * 0.02 * refl)
+    assert img[32, 32].tolist() == [int(f(255) * (f(0.02) * f(1.0))), int(f(255) * (f(0.02) * f(0.5))), int(f(255) * (f(0.02) * f(0.25))), 255]
+    # a sphere in front of the plane wins where it is closer; the plane shows elsewhere
+    objs2 = capi.FlatObjects([0, 0], [0, 0], [-5, -3], [0, 0.5], [1, 0], [0, 1], [0, 0], kind=np.array([1, 0], np.uint8), nx=[0, 0], ny=[0, 0], nz=[1, 0])
+    _, hit2 = oracle.render(objs2, lights, m, 64, 64, want_hit_idx=True)
+    assert hit2[32, 32] == 1 and hit2[0, 0] == 0
+    with pytest.raises(ValueError):
+        oracle.render(capi.FlatObjects([0], [0], [-5], [0], [1], [1], [1], kind=np.array([1], np.uint8)), lights, m, 8, 8)  # plane without normals
