@@ -283,10 +283,12 @@ def test_c3_full_size_general_path(gpu_ctx, oracle):
 
 def test_fuzz_scenes_cameras_modes(gpu_ctx, oracle):
     """60 random scenes: random sphere clouds (some around / behind the camera), mixed point/ambient lights (some inside spheres),
-    non-default and non-perspective camera matrices (rotation, shear, row 2 not constant), depth 1-3, shadows on/off, RGB8/RGBA8."""
-    rng = np.random.default_rng(2024)
+    non-default and non-perspective camera matrices (rotation, shear, row 2 not constant), depth 1-3, shadows on/off, RGB8/RGBA8,
+    every third scene with one or two planes (extension) mixed in.  RT_FUZZ_CASES / RT_FUZZ_SEED widen it for a soak run."""
+    rng = np.random.default_rng(int(os.environ.get("RT_FUZZ_SEED", "2024")))
     f = np.float32
-    for case in range(60):
+    npix = nlit = 0
+    for case in range(int(os.environ.get("RT_FUZZ_CASES", "60"))):
         w, h = int(rng.integers(1, 140)), int(rng.integers(1, 90))
         n, nl = int(rng.integers(0, 180)), int(rng.integers(0, 6))
         spread = f(rng.choice([3.0, 10.0, 40.0]))
@@ -296,10 +298,15 @@ def test_fuzz_scenes_cameras_modes(gpu_ctx, oracle):
         rad = (rng.random(n) ** 2 * spread * 0.4 + 1e-3).astype(f)
         refl = rng.random((3, n)).astype(f) * f(1.5)
         objs = capi.FlatObjects(cx, cy, cz, rad, refl[0], refl[1], refl[2])
+        if case % 3 == 1:
+            planes = [((rng.standard_normal(3) * spread).astype(f), rng.standard_normal(3).astype(f) + f(0.01), rng.random(3).astype(f))
+                      for _ in range(int(rng.integers(1, 3)))]
+            objs = _with_planes(objs, planes)
+            n = objs.n
         kind = (rng.random(nl) < 0.25).astype(np.uint8)
         lp = (rng.standard_normal((3, nl)) * spread).astype(f)
         if nl and n and case % 3 == 0:  # put the first light at a sphere centre
-            lp[0][0], lp[1][0], lp[2][0] = cx[0], cy[0], cz[0]
+            lp[0][0], lp[1][0], lp[2][0] = objs.cx[-1], objs.cy[-1], objs.cz[-1]
         lc = rng.random((3, nl)).astype(f)
         inten = (rng.random(nl) * spread * spread).astype(f)
         lights = capi.FlatLights(lp[0], lp[1], lp[2], lc[0], lc[1], lc[2], inten, kind=kind)
@@ -315,6 +322,9 @@ def test_fuzz_scenes_cameras_modes(gpu_ctx, oracle):
         ref, ref_hit = oracle.render(objs, lights, m, w, h, depth=depth, flags=flags & 1, channels=3 if flags & 2 else 4, want_hit_idx=True)
         _assert_same(gpu, ref, f"fuzz case {case}: {w}x{h} n={n} l={nl} depth={depth} flags={flags}")
         assert np.array_equal(hit, ref_hit), f"fuzz case {case}: hit index plane"
+        npix += w * h
+        nlit += int((hit >= 0).sum())
+    print(f"fuzz: {case + 1} scenes, {npix} pixels compared, {nlit} with a hit")
 
 
 def test_wavefront_many_lights_depth_and_bands(gpu_ctx, oracle):
