@@ -291,6 +291,8 @@ def test_fuzz_scenes_cameras_modes(gpu_ctx, oracle):
     for case in range(int(os.environ.get("RT_FUZZ_CASES", "60"))):
         w, h = int(rng.integers(1, 140)), int(rng.integers(1, 90))
         n, nl = int(rng.integers(0, 180)), int(rng.integers(0, 6))
+        if case % 10 == 9:  # several LDS chunks of spheres, more than 32 lights now and then
+            n, nl = int(rng.integers(1000, 3000)), int(rng.integers(0, 40))
         spread = f(rng.choice([3.0, 10.0, 40.0]))
         cx = (rng.standard_normal(n) * spread).astype(f)
         cy = (rng.standard_normal(n) * spread).astype(f)
