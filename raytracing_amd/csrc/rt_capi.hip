@@ -172,7 +172,7 @@ int32_t rt_scene_upload(rt_ctx* c, const rt_objects* o, const rt_lights* l)
     if (!msg.empty()) return fail(c, RT_ERR_INVALID, "rt_scene_upload: " + msg);
     RT_HIP(c, hipSetDevice(c->device));
 
-    // one packed allocation: filt | sph | sph_r | gen | refl | lpos | lcol | always | lfilt | lalways | lalways_off   (all 16-byte aligned)
+    // one packed allocation: filt | sph | sph_r | gen | refl | lpos | lcol | always | lfilt | lalways | lalways_off | pln | planes (all 16-byte aligned)
     const size_t np = (size_t)ps.n_pad, nl = (size_t)ps.n_lights, na = ps.always.size();
     const size_t off_filt = 0, off_sph = off_filt + np * 16, off_sph_r = off_sph + np * 16, off_gen = off_sph_r + np * 16, off_refl = off_gen + np * 16;
     const size_t off_lpos = off_refl + np * 16, off_lcol = off_lpos + (nl ? nl : 1) * 16, off_alw = off_lcol + (nl ? nl : 1) * 16;
@@ -199,7 +199,7 @@ int32_t rt_scene_upload(rt_ctx* c, const rt_objects* o, const rt_lights* l)
     std::memcpy(host.data() + off_pln, ps.pln.data(), np * 16);
     if (npl) std::memcpy(host.data() + off_planes, ps.planes.data(), npl * 4);
 
-    RT_HIP(c, hipStreamSynchronize(c->stream));  // no render may still read the old scene
+    RT_HIP(c, hipDeviceSynchronize());  // no render may still read the old scene (launches may sit on caller streams too)
     if (total > c->scene_bytes) {
         if (c->d_scene) RT_HIP(c, hipFree(c->d_scene));
         c->d_scene = nullptr;
