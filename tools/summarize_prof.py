@@ -46,6 +46,10 @@ for kname, d in per_kernel.items():
             out.append(f"VALU lane utilisation (SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU)) = {g('SQ_THREAD_CYCLES_VALU') / (64 * g('SQ_ACTIVE_INST_VALU')):.3f}")
         if g("GRBM_GUI_ACTIVE"):
             out.append(f"GRBM_GUI_ACTIVE / 8 XCDs = {g('GRBM_GUI_ACTIVE') / 8:.4e} cycles per dispatch")
+        if g("GRBM_GUI_ACTIVE") and g("SQ_WAVE_CYCLES"):
+            # SQ_WAVE_CYCLES counts quad-cycles summed over waves (MI355X_MICROARCH.md); 1024 SIMDs on the chip, 8 wave slots each
+            occ = g("SQ_WAVE_CYCLES") * 4 / (1024 * g("GRBM_GUI_ACTIVE") / 8)
+            out.append(f"wave occupancy (4 x SQ_WAVE_CYCLES / (1024 SIMDs x cycles)) = {occ:.2f} resident waves per SIMD on average ({occ / 8 * 100:.0f} % of the 8 slots)")
         if g("SQ_LDS_IDX_ACTIVE") is not None:
             out.append(f"LDS bank-conflict cycles / LDS active cycles = {g('SQ_LDS_BANK_CONFLICT', 0):.0f} / {g('SQ_LDS_IDX_ACTIVE'):.4e}")
         if g("TCC_EA0_WRREQ_sum") is not None:
