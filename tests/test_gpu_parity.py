@@ -294,10 +294,14 @@ def test_fuzz_scenes_cameras_modes(gpu_ctx, oracle):
         if case % 10 == 9:  # several LDS chunks of spheres, more than 32 lights now and then
             n, nl = int(rng.integers(1000, 3000)), int(rng.integers(0, 40))
         spread = f(rng.choice([3.0, 10.0, 40.0]))
+        if case % 7 == 3:  # wild scales: tiny and huge scenes, radii from far below to far above the spacing
+            spread = f(rng.choice([1e-3, 0.05, 700.0, 3e4]))
         cx = (rng.standard_normal(n) * spread).astype(f)
         cy = (rng.standard_normal(n) * spread).astype(f)
         cz = (rng.standard_normal(n) * spread - (0 if case % 5 == 0 else spread)).astype(f)
-        rad = (rng.random(n) ** 2 * spread * 0.4 + 1e-3).astype(f)
+        rad = (rng.random(n) ** 2 * spread * 0.4 + f(1e-3) * min(spread, f(1.0))).astype(f)
+        if case % 7 == 3 and n:
+            rad[:: 5] *= f(rng.choice([1e-3, 30.0]))
         refl = rng.random((3, n)).astype(f) * f(1.5)
         objs = capi.FlatObjects(cx, cy, cz, rad, refl[0], refl[1], refl[2])
         if case % 3 == 1:
