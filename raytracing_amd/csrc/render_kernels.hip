@@ -834,11 +834,11 @@ TilePlan plan_tiles(uint32_t w, uint32_t rows, uint32_t slots)
 
 namespace {
 
-// Resident workgroup slots of the current device for render_kernel<EMIT> (CUs x workgroups per CU), cached per device.
-template <bool EMIT>
-hipError_t resident_slots(uint32_t& slots)
+// Resident workgroup slots of the current device for a persistent kernel (CUs x workgroups of 256 threads per CU), cached per
+// (kernel, device) in `cache` (one array per kernel; a benign race: concurrent callers compute the same value).
+template <typename Kernel>
+hipError_t resident_slots(Kernel kernel, uint32_t (&cache)[64], uint32_t& slots)
 {
-    static uint32_t cache[64] = {};
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -846,7 +846,7 @@ hipError_t resident_slots(uint32_t& slots)
     if (cache[dev] == 0) {
         int cus = 0, per_cu = 0;
         if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
-        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, render_kernel<kB, EMIT>, kWaves * 64, 0)) != hipSuccess) return e;
+        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kWaves * 64, 0)) != hipSuccess) return e;
         if (cus <= 0 || per_cu <= 0) return hipErrorInvalidValue;
         cache[dev] = (uint32_t)cus * (uint32_t)per_cu;
     }
@@ -859,8 +859,9 @@ template <bool EMIT>
 hipError_t launch_primary(RenderArgs a, hipStream_t stream)
 {
     if (!a.tile_ctr) return hipErrorInvalidValue;
+    static uint32_t cache[64] = {};
     uint32_t slots = 0;
-    hipError_t e = resident_slots<EMIT>(slots);
+    hipError_t e = resident_slots(render_kernel<kB, EMIT>, cache, slots);
     if (e != hipSuccess) return e;
     const TilePlan tp = plan_tiles(a.w, a.y1 - a.y0, slots);
     a.strips = tp.strips;
@@ -894,16 +895,7 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
     uint32_t mask_slots = 0;
     if (shadows) {
         static uint32_t cache[64] = {};
-        int dev = 0, cus = 0, per_cu = 0;
-        if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
-        if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-        if (cache[dev] == 0) {
-            if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
-            if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, shadow_mask_kernel<kMaskP, kShadowB, kShadowChunk>, kWaves * 64, 0)) != hipSuccess) return e;
-            if (cus <= 0 || per_cu <= 0) return hipErrorInvalidValue;
-            cache[dev] = (uint32_t)cus * (uint32_t)per_cu;
-        }
-        mask_slots = cache[dev];
+        if ((e = resident_slots(shadow_mask_kernel<kMaskP, kShadowB, kShadowChunk>, cache, mask_slots)) != hipSuccess) return e;
     }
     RenderArgs a = args;
     const uint32_t shade_wgs = (uint32_t)((npix + kWaves * 64 * kShadeP - 1) / (kWaves * 64 * kShadeP));
