@@ -461,16 +461,15 @@ __device__ __forceinline__ void render_tile(const RenderArgs& A, float* s_x, flo
                 }
             }
             if (__builtin_amdgcn_ballot_w64(m >= 0.0f) != 0ull) {
-                // rare: some lane has a candidate in this block. Find the spheres, run the reference's exact test.
-                for (int b = 0; b < B; ++b) {
-                    const float4 q = A.filt[c0 + s0 + b];
-                    bool cand = false;
+                // rare: some lane has a candidate in this block. Find the spheres (constants still in registers), run the
+                // reference's exact test.
 #pragma unroll
-                    for (int p = 0; p < P; ++p) {
-                        float f = __builtin_fmaf(dx[p], q.x, __builtin_fmaf(dy[p], q.y, __builtin_fmaf(dz[p], q.z, -1.0f)));
-                        cand = cand || (f >= 0.0f);
-                    }
-                    if (__builtin_amdgcn_ballot_w64(cand) == 0ull) continue;
+                for (int b = 0; b < B; ++b) {
+                    float mb = -1.0f;
+#pragma unroll
+                    for (int p = 0; p < P; ++p)
+                        mb = __builtin_fmaxf(mb, __builtin_fmaf(dx[p], qx[b], __builtin_fmaf(dy[p], qy[b], __builtin_fmaf(dz[p], qz[b], -1.0f))));
+                    if (__builtin_amdgcn_ballot_w64(mb >= 0.0f) == 0ull) continue;
                     const int k = c0 + s0 + b;
                     const float4 s = A.sph[k];
 #pragma unroll
