@@ -156,3 +156,22 @@ def test_tile_plan_covers_every_band_exactly_once():
     assert big["rows4"] == 1824 and big["rows2"] == 216 and big["tiles1"] == 60 * 30
     band = capi.tile_plan(3840, 270, 1280)
     assert band["rows4"] == 0 and band["tiles2"] == 60 * 34 and band["tiles1"] == 0
+
+
+def test_cpp_scene_generator_matches_python():
+    """raytracing_amd/host/scenegen.hpp (used by the native harness examples/bench_scene) reproduces SCENE-GEN v1 bit for bit."""
+    import subprocess
+    exe = os.path.join(ROOT, "examples", "bench_scene")
+    assert os.path.exists(exe), "build it first: make -C examples (done by __graft_entry__.build())"
+    for name in ("C3", "C5"):
+        out = subprocess.run([exe, "--scene", name], capture_output=True, text=True, timeout=60, check=True).stdout.split("\n")
+        _, _, objs, lights = scenegen.config(name)
+        sph = [l.split()[1:] for l in out if l.startswith("S ")]
+        lts = [l.split()[1:] for l in out if l.startswith("L ")]
+        assert len(sph) == objs.n and len(lts) == lights.n
+        got = np.array([[int(v, 16) for v in row] for row in sph], dtype=np.uint32)
+        want = np.stack([a.view(np.uint32) for a in (objs.cx, objs.cy, objs.cz, objs.radius, objs.refl_r, objs.refl_g, objs.refl_b)], axis=1)
+        assert np.array_equal(got, want)
+        gotl = np.array([[int(v, 16) for v in row] for row in lts], dtype=np.uint32)
+        wantl = np.stack([a.view(np.uint32) for a in (lights.px, lights.py, lights.pz, lights.intensity)], axis=1)
+        assert np.array_equal(gotl, wantl)

@@ -485,3 +485,22 @@ def test_plane_extension(gpu_ctx, oracle):
     bad = capi.FlatObjects([0], [0], [-5], [0], [1], [1], [1], kind=np.array([1], np.uint8))
     with pytest.raises(capi.RtError):
         gpu_ctx.scene_upload(bad, fl)  # plane without normal arrays
+
+
+def test_native_bench_harness(tmp_path, gpu_ctx):
+    """examples/bench_scene (C++: SCENE-GEN, C ABI, page-locked frame store, no Python) renders the same bytes as the Python path."""
+    import subprocess
+    exe = os.path.abspath(os.path.join(os.path.dirname(GOLDEN), "..", "examples", "bench_scene"))
+    assert os.path.exists(exe), "build it first: make -C examples (done by __graft_entry__.build())"
+    for name, shadows in (("C3", 0), ("C5", 1)):
+        dump = tmp_path / f"{name}.rgba"
+        r = subprocess.run([exe, name, "2", str(shadows), "1", str(dump)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert "primary rays/s" in r.stdout
+        w, h, objs, lights = scenegen.config(name)
+        gpu_ctx.scene_upload(objs, lights)
+        m = capi.camera_transform(*capi.camera_default(), np.float32(w) / np.float32(h))
+        ref = gpu_ctx.render(m, w, h, 1, capi.RT_SHADOWS if shadows else 0)
+        got = np.fromfile(dump, dtype=np.uint8).reshape(h, w, 4)
+        _assert_same(got, ref, f"bench_scene {name}")
+    assert subprocess.run([exe, "C9"], capture_output=True, timeout=60).returncode == 2
