@@ -799,7 +799,10 @@ __global__ __launch_bounds__(kWaves * 64) void shade_iter_kernel(const RenderArg
 
 inline bool is_general(const RenderArgs& a) { return a.depth > 1u || (a.flags & RT_SHADOWS) != 0u; }
 
-constexpr int kB = 8;       // spheres per wave vote in the primary loop (sweep in profiles/r01_tuning.md)
+#ifndef RT_B
+#define RT_B 16
+#endif
+constexpr int kB = RT_B;       // spheres per wave vote in the primary loop (sweep in profiles/r01_tuning.md)
 constexpr int kShadeP = 2;  // records per lane in shade_iter_kernel
 #ifndef RT_MASK_P
 #define RT_MASK_P 4

@@ -13,7 +13,10 @@ struct f4 {
 };
 
 // Spheres are padded to a multiple of this many entries so the filter loop never needs a bounds check.
-constexpr int kSphereBlockPad = 16;
+#ifndef RT_PAD
+#define RT_PAD 16
+#endif
+constexpr int kSphereBlockPad = RT_PAD;
 
 struct PreparedScene {
     int32_t n = 0;       // elements (renderer.rs:37)

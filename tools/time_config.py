@@ -20,6 +20,11 @@ out = torch.zeros(((y1 - y0), w, 4), dtype=torch.uint8, device="cuda")
 flags = capi.RT_SHADOWS if a.shadows else 0
 with capi.Context(0) as ctx:
     ctx.scene_upload(objs, lights)
+    import time
+    t_end = time.perf_counter() + 0.06  # bring the clocks out of idle first (a cold GPU is ~15 % slower for the first tens of ms)
+    while time.perf_counter() < t_end:
+        ctx.render_rows_device(m, w, h, y0, y1, a.depth, flags, out.data_ptr())
+        ctx.last_kernel_ms()
     ms = []
     for _ in range(a.frames + 1):
         ctx.render_rows_device(m, w, h, y0, y1, a.depth, flags, out.data_ptr())
