@@ -818,8 +818,9 @@ TilePlan plan_tiles(uint32_t w, uint32_t rows, uint32_t slots)
     TilePlan tp;
     tp.strips = (w + kWaves * kLX - 1) / (kWaves * kLX);
     const uint64_t tiles16 = (uint64_t)tp.strips * ((rows + 15) / 16);
-    if (tiles16 < 2ull * slots) {
-        // a launch with few tiles (a row band of a multi-GPU split): 8-row tiles fill the chip better (profiles/r01_tuning.md)
+    if (tiles16 < slots) {
+        // a launch with less than one 16-row tile per resident workgroup (the band of one of 8 ranks): 8-row tiles fill the chip
+        // better (135 rows: 0.057 vs 0.068 ms); from one tile per workgroup on the sectioned queue wins (540 rows: 0.154 vs 0.157 ms)
         tp.rows4 = 0;
         tp.rows2 = (rows + 7) / 8 * 8;
     } else {
