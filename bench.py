@@ -64,6 +64,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
+        # the band / frame buffers live for the whole run, so the process group need not pin them to its stream per call
+        os.environ.setdefault("TORCH_NCCL_AVOID_RECORD_STREAMS", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     w, h, objs, lights = scenegen.config(args.config)
@@ -84,36 +86,105 @@ def main():
     # Several ranks: every rank renders only a band (270 rows at 8 GPUs), a launch too small to fill the chip on its own, so
     # frames rotate over three slots = three streams: the render of frame k+1 overlaps the drain of frame k and the RCCL gather
     # of frame k (measured on one GPU with 270-row bands: 98 -> 76 us per frame, tools/two_stream.py).
-    slots = 3 if use_dist else 1
+    slots = int(os.environ.get("BENCH_SLOTS", "3")) if use_dist else 1
     streams = [torch.cuda.Stream(dev) for _ in range(slots)]
     torch.cuda.set_stream(streams[0])
     band_bufs = [torch.zeros((rows_max, w, 4), dtype=torch.uint8, device=dev) for _ in range(slots)]
-    # rank 0 receives every band straight into its place in a [h, w, 4] frame (one frame per slot): the collective assembles the
-    # image, no copy follows (the configs' heights divide by 1/2/4/8; otherwise separate buffers + bands.assemble)
+    # BENCH_GATHER=rccl (default): grouped ncclSend/ncclRecv called directly (raytracing_amd.rccl_gather), rank 0 renders its band in
+    # place and receives the peers' bands straight into their rows of a [h, w, 4] frame (one frame per slot); everything of a frame
+    # is enqueued on that frame's stream, so the host spends a few C calls per step.  BENCH_GATHER=torch: torch.distributed.gather
+    # through bands.GatherPipeline (the same traffic; ~35-60 us more host time per step on rank 0, measured with tools/step_cost_probe.py).
+    gather_mode = os.environ.get("BENCH_GATHER", "rccl") if use_dist else "none"
+    if gather_mode not in ("none", "rccl", "torch"):
+        raise SystemExit("BENCH_GATHER must be rccl or torch")
+    frames = [torch.zeros((h, w, 4), dtype=torch.uint8, device=dev) for _ in range(slots)] if (use_dist and rank == 0) else []
+    rccl = None
+    pipe = None
     gather_lists = [None] * slots
-    if use_dist and rank == 0:
-        for s_ in range(slots):
-            frame = torch.zeros((h, w, 4), dtype=torch.uint8, device=dev)
-            views = bands.frame_gather_list(frame, h, world) if rows_max * world == h else None  # (a band rehearsal has a short band)
-            gather_lists[s_] = views or [torch.empty_like(band_bufs[0]) for _ in range(world)]
-    pipe = bands.GatherPipeline(world, rank, slots=slots, always_collective=use_dist)
+    if gather_mode == "rccl":
+        # Self-check before anything is timed: every rank fills its band with (rank + 1), the bands are gathered, rank 0 looks at its
+        # frame.  Any failure on any rank (an RCCL error, a wrong byte) makes ALL ranks fall back to torch.distributed.gather.
+        ok = 1
+        try:
+            from raytracing_amd import rccl_gather
+            rccl = rccl_gather.RcclBandGather(world, rank, local_rank)
+            if world > 1:
+                band_bufs[0].fill_(rank + 1)
+                if rank == 0:
+                    frames[0].zero_()
+                    frames[0][y0:y1].fill_(1)
+                torch.cuda.synchronize(dev)
+                rccl.gather(h, w, streams[0].cuda_stream, band_ptr=0 if rank == 0 else band_bufs[0].data_ptr(), frame_ptr=frames[0].data_ptr() if rank == 0 else 0)
+                streams[0].synchronize()
+                if rank == 0:
+                    for r in range(world):
+                        a, b = bands.band_rows(h, world, r)
+                        if not bool((frames[0][a:b] == r + 1).all()):
+                            ok = 0
+                band_bufs[0].zero_()
+        except Exception as e:  # noqa: BLE001 - whatever went wrong, the proven path takes over
+            print("rank %d: direct RCCL gather unavailable (%s), falling back to torch.distributed.gather" % (rank, e), file=sys.stderr)
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 0:
+            if rccl is not None:
+                rccl.close()
+            rccl = None
+            gather_mode = "torch"
+    if gather_mode == "torch":
+        if rank == 0:
+            for s_ in range(slots):
+                views = bands.frame_gather_list(frames[s_], h, world) if rows_max * world == h else None  # (a band rehearsal has a short band)
+                gather_lists[s_] = views or [torch.empty_like(band_bufs[0]) for _ in range(world)]
+        pipe = bands.GatherPipeline(world, rank, slots=slots, always_collective=True)
+    comm_stream = torch.cuda.Stream(dev) if (gather_mode == "rccl" and os.environ.get("BENCH_COMM_STREAM", "0") == "1") else None
+    rendered = [torch.cuda.Event() for _ in range(slots)]
+    gathered = [torch.cuda.Event() for _ in range(slots)]
     frame_no = [0]
+    row_bytes = w * 4
+    band_bytes = (y1 - y0) * row_bytes
 
     def step(ev=None):
         k = frame_no[0]
         frame_no[0] += 1
-        st = streams[k % slots]
-        with torch.cuda.stream(st):
-            s = pipe.begin(k)  # stream-level wait (on st) until the gather that last read band_bufs[s] is done
-            if ev is not None:
-                ev[0].record(st)
-            ctx.render_rows_device(m, w, h, y0, y1, 1, 0, band_bufs[s].data_ptr(), 0, st.cuda_stream)
-            if ev is not None:
-                ev[1].record(st)
-            pipe.submit(k, band_bufs[s], gather_lists[s])  # the collective is ordered after st's render of this frame
+        s = k % slots
+        st = streams[s]
+        if gather_mode == "torch":
+            with torch.cuda.stream(st):
+                pipe.begin(k)  # stream-level wait (on st) until the gather that last read band_bufs[s] is done
+                if ev is not None:
+                    ev[0].record(st)
+                ctx.render_rows_device(m, w, h, y0, y1, 1, 0, band_bufs[s].data_ptr(), 0, st.cuda_stream)
+                if ev is not None:
+                    ev[1].record(st)
+                pipe.submit(k, band_bufs[s], gather_lists[s])  # the collective is ordered after st's render of this frame
+            return
+        # in place on rank 0 of a real multi-rank run; into the band buffer otherwise
+        in_place = gather_mode == "rccl" and rank == 0 and rehearse_band <= 1
+        d_out = frames[s].data_ptr() + y0 * row_bytes if in_place else band_bufs[s].data_ptr()
+        if ev is not None:
+            ev[0].record(st)
+        ctx.render_rows_device(m, w, h, y0, y1, 1, 0, d_out, 0, st.cuda_stream)
+        if ev is not None:
+            ev[1].record(st)
+        if gather_mode == "rccl":
+            cs = st
+            if comm_stream is not None:  # all RCCL operations on one stream of their own, tied to the render streams by events
+                rendered[s].record(st)
+                comm_stream.wait_event(rendered[s])
+                cs = comm_stream
+            if world > 1:
+                rccl.gather(h, w, cs.cuda_stream, band_ptr=0 if rank == 0 else band_bufs[s].data_ptr(), frame_ptr=frames[s].data_ptr() if rank == 0 else 0)
+            else:  # one-rank rehearsal: the band travels rank 0 -> rank 0 through ncclSend/ncclRecv into its rows of the frame
+                rccl.loopback(band_bufs[s].data_ptr(), frames[s].data_ptr() + y0 * row_bytes, band_bytes, cs.cuda_stream)
+            if comm_stream is not None:
+                gathered[s].record(comm_stream)
+                st.wait_event(gathered[s])  # the next render into this slot's buffers comes after this gather
 
     def fence():
-        pipe.drain()
+        if pipe is not None:
+            pipe.drain()
         torch.cuda.synchronize(dev)
         if use_dist:
             dist.barrier()
@@ -136,8 +207,11 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(events[k])
+    t_issued = time.perf_counter()
     fence()
     t1 = time.perf_counter()
+    print("rank %d: host issued %d steps in %.3f ms (%.1f us per step), all done after %.3f ms" %
+          (rank, args.steps, (t_issued - t0) * 1e3, (t_issued - t0) * 1e6 / max(1, args.steps), (t1 - t0) * 1e3), file=sys.stderr)
     elapsed = t1 - t0
     kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)  # HIP events on the launch stream
 
@@ -166,7 +240,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic (SCENE-GEN v1, PCG32 seed 42)",
             "config": {"workload": "%s: %dx%d frame, %d spheres, %d point lights, depth 1, RGBA8 out" % (args.config, w, h, objs.n, lights.n),
-                       "parallelism": ("row bands x%d, RCCL gather to rank 0, %d frames in flight" % (world, slots)) if use_dist else "one rank, whole frame, one stream", "kernel": "render_kernel<primary>"},
+                       "parallelism": ("row bands x%d, RCCL gather to rank 0 (%s), %d frames in flight" % (world, "grouped ncclSend/ncclRecv" if gather_mode == "rccl" else "torch.distributed.gather", slots)) if use_dist else "one rank, whole frame, one stream", "kernel": "render_kernel<primary>"},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
                          "kernel_ms": kern_ms, "kernel_ms_max_over_ranks": kern_ms_max,
@@ -183,6 +257,8 @@ def main():
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     ctx.close()
+    if rccl is not None:
+        rccl.close()
     if use_dist:
         dist.destroy_process_group()
 

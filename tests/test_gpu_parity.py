@@ -504,3 +504,29 @@ def test_native_bench_harness(tmp_path, gpu_ctx):
         got = np.fromfile(dump, dtype=np.uint8).reshape(h, w, 4)
         _assert_same(got, ref, f"bench_scene {name}")
     assert subprocess.run([exe, "C9"], capture_output=True, timeout=60).returncode == 2
+
+
+def test_rccl_band_gather_self_send(gpu_ctx, oracle):
+    """raytracing_amd.rccl_gather on one GPU: a one-rank RCCL communicator where rank 0 sends its band to itself and receives it into
+    its rows of the frame — the exact ncclSend / ncclRecv / group calls a peer and the root make in a multi-GPU run."""
+    import torch
+    from raytracing_amd import rccl_gather
+    w, h = 640, 360
+    objs, lights = scenegen.generate(w, h, 150, 3, seed=88)
+    gpu_ctx.scene_upload(objs, lights)
+    m = _cam(oracle, w, h)
+    ref = gpu_ctx.render(m, w, h)
+    g = rccl_gather.RcclBandGather(1, 0, 0)
+    try:
+        assert g.plan(h, w) == [(0, h, h * w * 4)]
+        st = torch.cuda.Stream()
+        band = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        frame = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        for _ in range(3):  # several frames back to back on one stream: render -> gather is plain stream order
+            gpu_ctx.render_rows_device(m, w, h, 0, h, 1, 0, band.data_ptr(), 0, st.cuda_stream)
+            g.gather(h, w, st.cuda_stream, band_ptr=band.data_ptr(), frame_ptr=frame.data_ptr(), self_send=True)
+        st.synchronize()
+        _assert_same(frame.cpu().numpy(), ref, "frame assembled by ncclSend/ncclRecv")
+        g.gather(h, w, st.cuda_stream, frame_ptr=frame.data_ptr())  # one rank, no self-send: nothing to do
+    finally:
+        g.close()
