@@ -87,7 +87,7 @@ def main():
     # frames rotate over three slots = three streams: the render of frame k+1 overlaps the drain of frame k and the RCCL gather
     # of frame k (measured on one GPU with 270-row bands: 98 -> 76 us per frame, tools/two_stream.py).
     slots = int(os.environ.get("BENCH_SLOTS", "3")) if use_dist else 1
-    streams = [torch.cuda.Stream(dev) for _ in range(slots)]
+    streams = pick_concurrent_streams(torch, dev, slots) if slots > 1 else [torch.cuda.Stream(dev)]
     torch.cuda.set_stream(streams[0])
     band_bufs = [torch.zeros((rows_max, w, 4), dtype=torch.uint8, device=dev) for _ in range(slots)]
     # BENCH_GATHER=rccl (default): grouped ncclSend/ncclRecv called directly (raytracing_amd.rccl_gather), rank 0 renders its band in
@@ -261,6 +261,37 @@ def main():
         rccl.close()
     if use_dist:
         dist.destroy_process_group()
+
+
+def pick_concurrent_streams(torch, dev, n, candidates=16, pool=None):
+    """n streams that demonstrably run concurrently.  HIP multiplexes streams onto a few hardware queues (GPU_MAX_HW_QUEUES, 4 here) and
+    two streams that share one execute in order: a kernel trace of the band pipeline showed two of its three render streams on the same
+    queue, i.e. frames serialised.  Probe: a ~0.3 ms spin kernel on stream A, then an event on candidate B — if B's event completes while
+    A's spin is still running, A and B sit on different queues."""
+    pool = pool or [torch.cuda.Stream(dev) for _ in range(candidates)]
+    torch.cuda.synchronize(dev)
+
+    def independent(a, b):
+        done_a, done_b = torch.cuda.Event(), torch.cuda.Event()
+        with torch.cuda.stream(a):
+            torch.cuda._sleep(600000)
+            done_a.record(a)
+        done_b.record(b)  # nothing precedes it on b: completes at once unless b executes behind a
+        done_b.synchronize()
+        ok = not done_a.query()
+        done_a.synchronize()
+        return ok
+
+    chosen = [pool[0]]
+    for c in pool[1:]:
+        if len(chosen) == n:
+            break
+        if all(independent(a, c) and independent(c, a) for a in chosen):
+            chosen.append(c)
+    if len(chosen) < n:
+        print("only %d mutually concurrent streams found among %d candidates; reusing" % (len(chosen), candidates), file=sys.stderr)
+        chosen += [pool[i] for i in range(1, n - len(chosen) + 1)]
+    return chosen[:n]
 
 
 def pmc_traffic(config):

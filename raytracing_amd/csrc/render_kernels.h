@@ -45,6 +45,7 @@ struct RenderArgs {
     uint32_t strips;                  // 64-pixel column strips per tile row
     uint32_t tiles4, tiles2, tiles1;  // number of 16-, 8- and 4-row tiles, in queue order
     uint32_t rows4, rows2;            // rows covered by the first two sections
+    uint32_t static_grid;             // 1: plain grid, workgroup b renders tile b only (small bands); 0: persistent grid + tile queue
 };
 
 // How launch_render cuts a band of `rows` rows x `w` columns into the tile queue of the persistent primary kernel, given the number of

@@ -560,9 +560,13 @@ __global__ __launch_bounds__(kWaves * 64) void render_kernel(const RenderArgs A)
         }
     }
     const uint32_t n_tiles = A.tiles4 + A.tiles2 + A.tiles1;
-    for (;;) {
+    for (uint32_t round = 0;; ++round) {
         __syncthreads();  // s_tile of the previous round has been read by everyone (first round: the staged list is visible)
-        if (tid == 0) s_tile = atomicAdd(A.tile_ctr, 1u);
+        if (A.static_grid) {  // small band: one tile per workgroup, no queue (launch_primary)
+            if (tid == 0) s_tile = round == 0 ? blockIdx.x : n_tiles;
+        } else if (tid == 0) {
+            s_tile = atomicAdd(A.tile_ctr, 1u);
+        }
         __syncthreads();
         uint32_t t = s_tile;
         if (t >= n_tiles) break;
@@ -577,7 +581,7 @@ __global__ __launch_bounds__(kWaves * 64) void render_kernel(const RenderArgs A)
     }
     // every workgroup does exactly one failing fetch and then reports here, so the last one to arrive knows that nobody will
     // touch the queue again and resets it; the end of the kernel publishes the two stores to the next launch
-    if (tid == 0) {
+    if (tid == 0 && !A.static_grid) {
         if (atomicAdd(A.tile_ctr + 1, 1u) == gridDim.x - 1u) {
             atomicExch(A.tile_ctr, 0u);
             atomicExch(A.tile_ctr + 1, 0u);
@@ -874,7 +878,11 @@ hipError_t launch_primary(RenderArgs a, hipStream_t stream)
     a.tiles2 = tp.tiles2;
     a.tiles1 = tp.tiles1;
     const uint32_t n_tiles = a.tiles4 + a.tiles2 + a.tiles1;
-    const uint32_t grid = n_tiles < slots ? n_tiles : slots;
+    // A small band (8-row tiles only: at most ~2 tiles per resident workgroup) is launched as a plain grid, one tile per workgroup: the
+    // queue has nothing to balance there, and workgroups that leave as they finish let the RCCL kernels of a multi-GPU step in
+    // (band pipeline with a real RCCL kernel per frame: 84 vs 87 us per step; 135-row band alone 0.044 vs 0.051 ms).
+    a.static_grid = a.tiles4 == 0 ? 1u : 0u;
+    const uint32_t grid = (a.static_grid || n_tiles < slots) ? n_tiles : slots;
     hipLaunchKernelGGL((render_kernel<kB, EMIT>), dim3(grid), dim3(kWaves * 64), 0, stream, a);
     return hipGetLastError();
 }
