@@ -87,7 +87,11 @@ def main():
     # frames rotate over three slots = three streams: the render of frame k+1 overlaps the drain of frame k and the RCCL gather
     # of frame k (measured on one GPU with 270-row bands: 98 -> 76 us per frame, tools/two_stream.py).
     slots = int(os.environ.get("BENCH_SLOTS", "3")) if use_dist else 1
-    streams = pick_concurrent_streams(torch, dev, slots) if slots > 1 else [torch.cuda.Stream(dev)]
+    try:
+        streams = pick_concurrent_streams(torch, dev, slots) if slots > 1 else [torch.cuda.Stream(dev)]
+    except Exception as e:  # noqa: BLE001 - the probe is an optimisation; plain streams always work
+        print("rank %d: stream probe failed (%s), using plain streams" % (rank, e), file=sys.stderr)
+        streams = [torch.cuda.Stream(dev) for _ in range(slots)]
     torch.cuda.set_stream(streams[0])
     band_bufs = [torch.zeros((rows_max, w, 4), dtype=torch.uint8, device=dev) for _ in range(slots)]
     # BENCH_GATHER=rccl (default): grouped ncclSend/ncclRecv called directly (raytracing_amd.rccl_gather), rank 0 renders its band in
