@@ -85,7 +85,8 @@ def main():
     # One rank, one stream: launches run back to back and the per-launch HIP-event durations are exclusive (clean roofline).
     # Several ranks: every rank renders only a band (270 rows at 8 GPUs), a launch too small to fill the chip on its own, so
     # frames rotate over three slots = three streams: the render of frame k+1 overlaps the drain of frame k and the RCCL gather
-    # of frame k (measured on one GPU with 270-row bands: 98 -> 76 us per frame, tools/two_stream.py).
+    # of frame k (measured on one GPU with 270-row bands: 103 -> 72 us per frame, tools/two_stream.py).  The streams are probed
+    # for real concurrency (pick_concurrent_streams).
     slots = int(os.environ.get("BENCH_SLOTS", "3")) if use_dist else 1
     try:
         streams = pick_concurrent_streams(torch, dev, slots) if slots > 1 else [torch.cuda.Stream(dev)]
@@ -142,9 +143,6 @@ def main():
                 views = bands.frame_gather_list(frames[s_], h, world) if rows_max * world == h else None  # (a band rehearsal has a short band)
                 gather_lists[s_] = views or [torch.empty_like(band_bufs[0]) for _ in range(world)]
         pipe = bands.GatherPipeline(world, rank, slots=slots, always_collective=True)
-    comm_stream = torch.cuda.Stream(dev) if (gather_mode == "rccl" and os.environ.get("BENCH_COMM_STREAM", "0") == "1") else None
-    rendered = [torch.cuda.Event() for _ in range(slots)]
-    gathered = [torch.cuda.Event() for _ in range(slots)]
     frame_no = [0]
     row_bytes = w * 4
     band_bytes = (y1 - y0) * row_bytes
@@ -172,19 +170,11 @@ def main():
         ctx.render_rows_device(m, w, h, y0, y1, 1, 0, d_out, 0, st.cuda_stream)
         if ev is not None:
             ev[1].record(st)
-        if gather_mode == "rccl":
-            cs = st
-            if comm_stream is not None:  # all RCCL operations on one stream of their own, tied to the render streams by events
-                rendered[s].record(st)
-                comm_stream.wait_event(rendered[s])
-                cs = comm_stream
+        if gather_mode == "rccl":  # stream order: render k -> gather k -> (slots frames later) render k + slots
             if world > 1:
-                rccl.gather(h, w, cs.cuda_stream, band_ptr=0 if rank == 0 else band_bufs[s].data_ptr(), frame_ptr=frames[s].data_ptr() if rank == 0 else 0)
+                rccl.gather(h, w, st.cuda_stream, band_ptr=0 if rank == 0 else band_bufs[s].data_ptr(), frame_ptr=frames[s].data_ptr() if rank == 0 else 0)
             else:  # one-rank rehearsal: the band travels rank 0 -> rank 0 through ncclSend/ncclRecv into its rows of the frame
-                rccl.loopback(band_bufs[s].data_ptr(), frames[s].data_ptr() + y0 * row_bytes, band_bytes, cs.cuda_stream)
-            if comm_stream is not None:
-                gathered[s].record(comm_stream)
-                st.wait_event(gathered[s])  # the next render into this slot's buffers comes after this gather
+                rccl.loopback(band_bufs[s].data_ptr(), frames[s].data_ptr() + y0 * row_bytes, band_bytes, st.cuda_stream)
 
     def fence():
         if pipe is not None:
