@@ -45,10 +45,11 @@ struct rt_ctx {
     size_t rec_planes = 0;     // 4-byte planes of rec_capacity entries allocated after the 16-byte counter
     // tile-queue counters of the persistent primary kernel: a ring of slots (64 B apart), one per launch in flight
     uint32_t* d_tile_ctr = nullptr;
-    uint32_t tile_slot = 0;
+    hipStream_t tile_slot_stream[16] = {};  // slot i belongs to this stream (launches of one stream execute in order and can share it)
+    uint32_t tile_slots_used = 0;
 };
 
-static constexpr uint32_t kTileSlots = 16;  // launches of one context that may overlap on different streams
+static constexpr uint32_t kTileSlots = 16;  // distinct streams one context can be rendered on
 
 static thread_local std::string g_create_err;
 
@@ -261,7 +262,16 @@ static int32_t enqueue_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h
     a.out = static_cast<uint8_t*>(d_out);
     a.hit_idx = static_cast<int32_t*>(d_hit_idx);
     a.rec_count = nullptr; a.rec_pix = nullptr; a.rec_idx = nullptr; a.rec_t = nullptr;
-    a.tile_ctr = c->d_tile_ctr + (size_t)(c->tile_slot++ % kTileSlots) * 16;
+    {  // the tile-queue counters of this launch: one slot per stream, so kernels that can run concurrently never share a queue
+        uint32_t slot = 0;
+        while (slot < c->tile_slots_used && c->tile_slot_stream[slot] != st) ++slot;
+        if (slot == c->tile_slots_used) {
+            if (slot == kTileSlots) return fail(c, RT_ERR_TOO_LARGE, "a context can be rendered on at most 16 distinct streams");
+            c->tile_slot_stream[slot] = st;
+            ++c->tile_slots_used;
+        }
+        a.tile_ctr = c->d_tile_ctr + (size_t)slot * 16;
+    }
     a.strips = a.tiles4 = a.tiles2 = a.tiles1 = a.rows4 = a.rows2 = 0;
     a.rec_cap = 0; a.iter = 0; a.rec_state = nullptr; a.rec_occ = nullptr;
     if (render_needs_records(a)) {

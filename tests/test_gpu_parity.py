@@ -530,3 +530,35 @@ def test_rccl_band_gather_self_send(gpu_ctx, oracle):
         g.gather(h, w, st.cuda_stream, frame_ptr=frame.data_ptr())  # one rank, no self-send: nothing to do
     finally:
         g.close()
+
+
+def test_many_launches_in_flight_on_several_streams(oracle):
+    """Tile-queue counters are per stream: hundreds of band launches enqueued at once on three streams (the host far ahead of the GPU,
+    as in the multi-GPU pipeline) all produce the exact band; a 17th distinct stream on one context is refused."""
+    import torch
+    w, h = 1280, 720
+    objs, lights = scenegen.generate(w, h, 400, 3, seed=91)
+    m = _cam(oracle, w, h)
+    with capi.Context(0) as ctx:
+        ctx.scene_upload(objs, lights)
+        ref = ctx.render(m, w, h)
+        streams = [torch.cuda.Stream() for _ in range(3)]
+        cuts = [(0, 90), (90, 400), (400, 720)]  # a small band (plain grid) and two with the queue
+        outs = [[torch.zeros((b - a, w, 4), dtype=torch.uint8, device="cuda") for (a, b) in cuts] for _ in streams]
+        for k in range(240):
+            s = k % 3
+            a, b = cuts[(k // 3) % 3]
+            ctx.render_rows_device(m, w, h, a, b, 1, 0, outs[s][(k // 3) % 3].data_ptr(), 0, streams[s].cuda_stream)
+        torch.cuda.synchronize()
+        for s in range(3):
+            for (a, b), o in zip(cuts, outs[s]):
+                _assert_same(o.cpu().numpy(), ref[a:b], f"stream {s} rows {a}:{b}")
+        more = [torch.cuda.Stream() for _ in range(14)]  # 3 + the context's own + ... : fill the 16 slots, then one too many
+        buf = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        used = 4  # the three above and the context's own stream (ctx.render)
+        with pytest.raises(capi.RtError) as e:
+            for st in more:
+                ctx.render_rows_device(m, w, h, 0, 8, 1, 0, buf.data_ptr(), 0, st.cuda_stream)
+                used += 1
+        assert e.value.code == capi.RT_ERR_TOO_LARGE and used == 16
+        torch.cuda.synchronize()
