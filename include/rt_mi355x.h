@@ -11,6 +11,7 @@
  *   - a rt_ctx is bound to ONE device (one process per GPU; multi-GPU = one ctx per rank, row bands, see
  *     rt_render_rows*) and is NOT thread-safe (mirrors `&mut self` of Renderer::render, renderer.rs:32);
  *   - arrays passed in are borrowed for the duration of the call only;
+ *   - every entry point makes ctx's device current while it runs and restores the caller's current device before it returns;
  *   - there is no CPU fallback: without a usable gfx950 device rt_ctx_create fails with RT_ERR_NO_DEVICE.
  */
 #ifndef RT_MI355X_H
@@ -70,7 +71,7 @@ typedef struct rt_lights {
 
 typedef struct rt_ctx rt_ctx;
 
-/* library/ABI version string, static storage */
+/* library/ABI version string, static storage; "rt_mi355x 0.2": rt_objects carries plane normals (0.1 did not) */
 const char* rt_version(void);
 
 /* Replaces nothing in the reference (it owns no device state): creates the per-device context (stream, events, scene buffers). */

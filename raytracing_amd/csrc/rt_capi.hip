@@ -73,9 +73,35 @@ static int32_t fail_hip(rt_ctx* ctx, hipError_t e, const char* what)
         if (e_ != hipSuccess) return fail_hip(ctx, e_, #call); \
     } while (0)
 
+// Makes the context's device current for the duration of an entry point and puts the caller's device back afterwards
+// (a host with several contexts, or a framework that tracks its own current device, must not find it changed).
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t status = hipSuccess;
+    explicit DeviceGuard(int device)
+    {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) cur = -1;
+        if (cur != device) {
+            status = hipSetDevice(device);
+            if (status == hipSuccess) prev = cur;
+        }
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
+#define RT_DEVICE(ctx)                    \
+    DeviceGuard device_guard_((ctx)->device); \
+    RT_HIP(ctx, device_guard_.status)
+
 extern "C" {
 
-const char* rt_version(void) { return "rt_mi355x 0.1 (gfx950)"; }
+const char* rt_version(void) { return "rt_mi355x 0.2 (gfx950)"; }
 
 const char* rt_last_error(const rt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
 
@@ -129,7 +155,8 @@ int32_t rt_ctx_create(rt_ctx** out, int32_t device_id)
     rt_ctx* c = new (std::nothrow) rt_ctx();
     if (!c) return fail(nullptr, RT_ERR_HIP, "out of host memory");
     c->device = device_id;
-    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+    DeviceGuard guard(device_id);
+    if ((e = guard.status) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->ev_chunk[0], hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&c->ev_chunk[1], hipEventDisableTiming)) != hipSuccess ||
@@ -147,7 +174,7 @@ int32_t rt_ctx_create(rt_ctx** out, int32_t device_id)
 int32_t rt_ctx_destroy(rt_ctx* c)
 {
     if (!c) return RT_OK;
-    if (c->device >= 0) (void)hipSetDevice(c->device);
+    DeviceGuard guard(c->device >= 0 ? c->device : 0);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     if (c->d_scene) (void)hipFree(c->d_scene);
@@ -171,7 +198,7 @@ int32_t rt_scene_upload(rt_ctx* c, const rt_objects* o, const rt_lights* l)
     PreparedScene ps;
     std::string msg = prepare_scene(o, l, ps);
     if (!msg.empty()) return fail(c, RT_ERR_INVALID, "rt_scene_upload: " + msg);
-    RT_HIP(c, hipSetDevice(c->device));
+    RT_DEVICE(c);
 
     // one packed allocation: filt | sph | sph_r | gen | refl | lpos | lcol | always | lfilt | lalways | lalways_off | pln | planes (all 16-byte aligned)
     const size_t np = (size_t)ps.n_pad, nl = (size_t)ps.n_lights, na = ps.always.size();
@@ -315,7 +342,7 @@ int32_t rt_render_rows_device(rt_ctx* c, const float m[16], uint32_t w, uint32_t
     int32_t rc = check_render_args(c, m, w, h, y0, y1, depth, flags);
     if (rc != RT_OK) return rc;
     if (y1 > y0 && !d_out) return fail(c, RT_ERR_INVALID, "output pointer is null");
-    RT_HIP(c, hipSetDevice(c->device));
+    RT_DEVICE(c);
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : c->stream;
     RT_HIP(c, hipEventRecord(c->ev0, st));
     rc = enqueue_rows(c, m, w, h, y0, y1, depth, flags, d_out, d_hit_idx, st);
@@ -332,7 +359,7 @@ int32_t rt_render_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h, uin
     if (rc != RT_OK) return rc;
     if (y1 == y0) return RT_OK;
     if (!out_host) return fail(c, RT_ERR_INVALID, "output pointer is null");
-    RT_HIP(c, hipSetDevice(c->device));
+    RT_DEVICE(c);
     const size_t npix = (size_t)(y1 - y0) * w;
     const size_t bytes = npix * ((flags & RT_OUT_RGB8) ? 3 : 4);
     if (bytes > c->d_out_bytes) {
@@ -361,7 +388,11 @@ int32_t rt_render_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h, uin
         const size_t off = (size_t)r0 * w;
         rc = enqueue_rows(c, m, w, h, y0 + r0, y0 + r1, depth, flags, static_cast<char*>(c->d_out) + off * bpp,
                           hit_idx_host ? static_cast<char*>(c->d_hit) + off * 4 : nullptr, c->stream);
-        if (rc != RT_OK) return rc;
+        if (rc != RT_OK) {  // copies of earlier chunks may still be writing the caller's buffer: let them finish before handing it back
+            (void)hipStreamSynchronize(c->copy_stream);
+            (void)hipStreamSynchronize(c->stream);
+            return rc;
+        }
         RT_HIP(c, hipEventRecord(c->ev_chunk[k], c->stream));
         RT_HIP(c, hipStreamWaitEvent(c->copy_stream, c->ev_chunk[k], 0));
         RT_HIP(c, hipMemcpyAsync(out_host + off * bpp, static_cast<char*>(c->d_out) + off * bpp, (size_t)(r1 - r0) * w * bpp, hipMemcpyDeviceToHost, c->copy_stream));
@@ -385,7 +416,7 @@ int32_t rt_host_alloc(rt_ctx* c, size_t bytes, void** out)
     if (!c) return RT_ERR_INVALID;
     if (!out || bytes == 0) return fail(c, RT_ERR_INVALID, "rt_host_alloc: empty request");
     *out = nullptr;
-    RT_HIP(c, hipSetDevice(c->device));
+    RT_DEVICE(c);
     RT_HIP(c, hipHostMalloc(out, bytes, hipHostMallocDefault));
     return RT_OK;
 }
@@ -394,7 +425,7 @@ int32_t rt_host_free(rt_ctx* c, void* p)
 {
     if (!c) return RT_ERR_INVALID;
     if (!p) return RT_OK;
-    RT_HIP(c, hipSetDevice(c->device));
+    RT_DEVICE(c);
     RT_HIP(c, hipStreamSynchronize(c->copy_stream));  // no copy of this ctx may still target the block
     RT_HIP(c, hipHostFree(p));
     return RT_OK;
@@ -404,7 +435,7 @@ int32_t rt_last_kernel_ms(rt_ctx* c, float* ms)
 {
     if (!c || !ms) return RT_ERR_INVALID;
     if (!c->timed) return fail(c, RT_ERR_INVALID, "no render has been enqueued on this context");
-    RT_HIP(c, hipSetDevice(c->device));
+    RT_DEVICE(c);
     RT_HIP(c, hipEventSynchronize(c->ev1));
     RT_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
     return RT_OK;
