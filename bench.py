@@ -316,8 +316,26 @@ def cpu_baseline(objs, lights, m, w, h):
     orc.render(objs, lights, m, w, h, row_step=row_step, nthreads=threads)
     dt = time.perf_counter() - t0
     rows = (h + row_step - 1) // row_step
+    # the same oracle on ONE thread, on a 16 x sparser sample (SURVEY 8d asks for both figures)
+    row_step1 = 32
+    t0 = time.perf_counter()
+    orc.render(objs, lights, m, w, h, row_step=row_step1, nthreads=1)
+    dt1 = time.perf_counter() - t0
+    rows1 = (h + row_step1 - 1) // row_step1
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     return {"value": rows * w / dt, "unit": "rays/s", "cores": threads, "kind": "port",
-            "sample": "every %dth row of the same frame (%d rows x %d px), %d threads, %.2f s wall" % (row_step, rows, w, threads, dt)}
+            "sample": "every %dth row of the same frame (%d rows x %d px), %d threads, %.2f s wall" % (row_step, rows, w, threads, dt),
+            "value_one_thread": rows1 * w / dt1,
+            "sample_one_thread": "every %dth row (%d rows x %d px), 1 thread, %.2f s wall" % (row_step1, rows1, w, dt1),
+            "host": "%s, %d logical CPUs visible" % (model, os.cpu_count() or 0),
+            "note": "C restatement of the reference (oracle/rt_oracle.c), not the Rust binary: no Rust toolchain in the image"}
 
 
 if __name__ == "__main__":
