@@ -103,7 +103,11 @@ def main():
     if gather_mode not in ("none", "rccl", "torch"):
         raise SystemExit("BENCH_GATHER must be rccl or torch")
     frames = [torch.zeros((h, w, 4), dtype=torch.uint8, device=dev) for _ in range(slots)] if (use_dist and rank == 0) else []
-    rccl = None
+    rccl = None   # one communicator per slot: RCCL orders the operations of ONE communicator among themselves, so with a single
+    # communicator the gathers of consecutive frames would run strictly one after the other (each pays its launch / hand-shake latency
+    # serially); with a communicator per slot the gather of frame k+1 can start while frame k is still on the links.  All ranks issue
+    # the frames, hence the communicators, in the same order.  BENCH_COMMS=1 restores the single communicator.
+    n_comms = max(1, min(slots, int(os.environ.get("BENCH_COMMS", str(slots)))))
     pipe = None
     gather_lists = [None] * slots
     if gather_mode == "rccl":
@@ -112,29 +116,29 @@ def main():
         ok = 1
         try:
             from raytracing_amd import rccl_gather
-            rccl = rccl_gather.RcclBandGather(world, rank, local_rank)
-            if world > 1:
-                band_bufs[0].fill_(rank + 1)
+            rccl = [rccl_gather.RcclBandGather(world, rank, local_rank) for _ in range(n_comms)]
+            for ci, comm in enumerate(rccl if world > 1 else []):
+                band_bufs[0].fill_(rank + 1 + ci)
                 if rank == 0:
                     frames[0].zero_()
-                    frames[0][y0:y1].fill_(1)
+                    frames[0][y0:y1].fill_(1 + ci)
                 torch.cuda.synchronize(dev)
-                rccl.gather(h, w, streams[0].cuda_stream, band_ptr=0 if rank == 0 else band_bufs[0].data_ptr(), frame_ptr=frames[0].data_ptr() if rank == 0 else 0)
+                comm.gather(h, w, streams[0].cuda_stream, band_ptr=0 if rank == 0 else band_bufs[0].data_ptr(), frame_ptr=frames[0].data_ptr() if rank == 0 else 0)
                 streams[0].synchronize()
                 if rank == 0:
                     for r in range(world):
                         a, b = bands.band_rows(h, world, r)
-                        if not bool((frames[0][a:b] == r + 1).all()):
+                        if not bool((frames[0][a:b] == r + 1 + ci).all()):
                             ok = 0
-                band_bufs[0].zero_()
+            band_bufs[0].zero_()
         except Exception as e:  # noqa: BLE001 - whatever went wrong, the proven path takes over
             print("rank %d: direct RCCL gather unavailable (%s), falling back to torch.distributed.gather" % (rank, e), file=sys.stderr)
             ok = 0
         flag = torch.tensor([ok], dtype=torch.int32, device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag[0]) == 0:
-            if rccl is not None:
-                rccl.close()
+            for comm in rccl or []:
+                comm.close()
             rccl = None
             gather_mode = "torch"
     if gather_mode == "torch":
@@ -171,10 +175,11 @@ def main():
         if ev is not None:
             ev[1].record(st)
         if gather_mode == "rccl":  # stream order: render k -> gather k -> (slots frames later) render k + slots
+            comm = rccl[s % n_comms]
             if world > 1:
-                rccl.gather(h, w, st.cuda_stream, band_ptr=0 if rank == 0 else band_bufs[s].data_ptr(), frame_ptr=frames[s].data_ptr() if rank == 0 else 0)
+                comm.gather(h, w, st.cuda_stream, band_ptr=0 if rank == 0 else band_bufs[s].data_ptr(), frame_ptr=frames[s].data_ptr() if rank == 0 else 0)
             else:  # one-rank rehearsal: the band travels rank 0 -> rank 0 through ncclSend/ncclRecv into its rows of the frame
-                rccl.loopback(band_bufs[s].data_ptr(), frames[s].data_ptr() + y0 * row_bytes, band_bytes, st.cuda_stream)
+                comm.loopback(band_bufs[s].data_ptr(), frames[s].data_ptr() + y0 * row_bytes, band_bytes, st.cuda_stream)
 
     def fence():
         if pipe is not None:
@@ -234,7 +239,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic (SCENE-GEN v1, PCG32 seed 42)",
             "config": {"workload": "%s: %dx%d frame, %d spheres, %d point lights, depth 1, RGBA8 out" % (args.config, w, h, objs.n, lights.n),
-                       "parallelism": ("row bands x%d, RCCL gather to rank 0 (%s), %d frames in flight" % (world, "grouped ncclSend/ncclRecv" if gather_mode == "rccl" else "torch.distributed.gather", slots)) if use_dist else "one rank, whole frame, one stream", "kernel": "render_kernel<primary>"},
+                       "parallelism": ("row bands x%d, RCCL gather to rank 0 (%s), %d frames in flight" % (world, ("grouped ncclSend/ncclRecv, %d communicators" % n_comms) if gather_mode == "rccl" else "torch.distributed.gather", slots)) if use_dist else "one rank, whole frame, one stream", "kernel": "render_kernel<primary>"},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
                          "kernel_ms": kern_ms, "kernel_ms_max_over_ranks": kern_ms_max,
@@ -251,8 +256,8 @@ def main():
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     ctx.close()
-    if rccl is not None:
-        rccl.close()
+    for comm in rccl or []:
+        comm.close()
     if use_dist:
         dist.destroy_process_group()
 
