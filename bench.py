@@ -166,6 +166,11 @@ def main():
                     ev[1].record(st)
                 pipe.submit(k, band_bufs[s], gather_lists[s])  # the collective is ordered after st's render of this frame
             return
+        render_part(s, st, ev)
+        if gather_mode == "rccl":  # stream order: render k -> gather k -> (slots frames later) render k + slots
+            gather_part(s, st)
+
+    def render_part(s, st, ev=None):
         # in place on rank 0 of a real multi-rank run; into the band buffer otherwise
         in_place = gather_mode == "rccl" and rank == 0 and rehearse_band <= 1
         d_out = frames[s].data_ptr() + y0 * row_bytes if in_place else band_bufs[s].data_ptr()
@@ -174,12 +179,13 @@ def main():
         ctx.render_rows_device(m, w, h, y0, y1, 1, 0, d_out, 0, st.cuda_stream)
         if ev is not None:
             ev[1].record(st)
-        if gather_mode == "rccl":  # stream order: render k -> gather k -> (slots frames later) render k + slots
-            comm = rccl[s % n_comms]
-            if world > 1:
-                comm.gather(h, w, st.cuda_stream, band_ptr=0 if rank == 0 else band_bufs[s].data_ptr(), frame_ptr=frames[s].data_ptr() if rank == 0 else 0)
-            else:  # one-rank rehearsal: the band travels rank 0 -> rank 0 through ncclSend/ncclRecv into its rows of the frame
-                comm.loopback(band_bufs[s].data_ptr(), frames[s].data_ptr() + y0 * row_bytes, band_bytes, st.cuda_stream)
+
+    def gather_part(s, st):
+        comm = rccl[s % n_comms]
+        if world > 1:
+            comm.gather(h, w, st.cuda_stream, band_ptr=0 if rank == 0 else band_bufs[s].data_ptr(), frame_ptr=frames[s].data_ptr() if rank == 0 else 0)
+        else:  # one-rank rehearsal: the band travels rank 0 -> rank 0 through ncclSend/ncclRecv into its rows of the frame
+            comm.loopback(band_bufs[s].data_ptr(), frames[s].data_ptr() + y0 * row_bytes, band_bytes, st.cuda_stream)
 
     def fence():
         if pipe is not None:
@@ -214,6 +220,27 @@ def main():
     elapsed = t1 - t0
     kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)  # HIP events on the launch stream
 
+    # After the timed region, multi-rank runs only: the two halves of a step on their own (same streams, same rotation), so that the
+    # JSON line says which side bounds the pipeline - the renders of the bands or the gather over the links.  Not part of `value`.
+    diag = None
+    if gather_mode == "rccl":
+        n_diag = 120
+        t_r0 = time.perf_counter()
+        for k in range(n_diag):
+            render_part(k % slots, streams[k % slots])
+        fence()
+        t_r1 = time.perf_counter()
+        for k in range(n_diag):
+            gather_part(k % slots, streams[k % slots])
+        fence()
+        t_g1 = time.perf_counter()
+        d = torch.tensor([t_r1 - t_r0, t_g1 - t_r1], dtype=torch.float64, device=dev)
+        dist.all_reduce(d, op=dist.ReduceOp.MAX)
+        peer_bytes = bands.max_band_rows(h, world) * row_bytes if world > 1 else band_bytes
+        diag = {"render_only_us_per_step": float(d[0]) / n_diag * 1e6, "gather_only_us_per_step": float(d[1]) / n_diag * 1e6,
+                "gather_only_GBps_per_peer_link": peer_bytes / (float(d[1]) / n_diag) / 1e9,
+                "note": "%d steps each, after the timed region, same streams; the fence (device sync + barrier) is inside both figures" % n_diag}
+
     tmax = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -246,6 +273,8 @@ def main():
                          "flops_counted": "%d per (pixel,sphere) filter test x %d tests per launch" % (FLOPS_PER_TEST, my_tests)},
         }
         out["roofline"]["traffic"], out["roofline"]["traffic_note"] = pmc_traffic(args.config)
+        if diag is not None:
+            out["diagnostics"] = diag
         if rehearse_band > 1:
             out["rehearsal"] = "one rank rendering the band of 1/%d of the frame: host issue-rate probe, not a result" % rehearse_band
         if slots > 1:

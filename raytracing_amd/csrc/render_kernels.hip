@@ -822,11 +822,18 @@ TilePlan plan_tiles(uint32_t w, uint32_t rows, uint32_t slots)
     TilePlan tp;
     tp.strips = (w + kWaves * kLX - 1) / (kWaves * kLX);
     const uint64_t tiles16 = (uint64_t)tp.strips * ((rows + 15) / 16);
-    if (tiles16 < slots) {
-        // a launch with less than one 16-row tile per resident workgroup (the band of one of 8 ranks): 8-row tiles fill the chip
-        // better (135 rows: 0.057 vs 0.068 ms); from one tile per workgroup on the sectioned queue wins (540 rows: 0.154 vs 0.157 ms)
+    if (tiles16 * 8 <= (uint64_t)slots * 5) {
+        // a very small launch (well under one 16-row tile per resident workgroup): 8-row tiles fill the chip better
+        // (135 rows of a 4K frame alone on a stream: 0.050 vs 0.065 ms)
         tp.rows4 = 0;
         tp.rows2 = (rows + 7) / 8 * 8;
+    } else if (tiles16 < 3ull * slots) {
+        // up to three 16-row tiles per resident workgroup (the band of one of 4 or 8 ranks at 4K): 16-row tiles only, the efficient
+        // shape (one broadcast LDS read per 16 FMAs).  Such launches are what a multi-GPU host keeps several of in flight, and then
+        // the next launch covers the tail of this one: three streams, 270 rows 73.9 -> 68.3 us per frame against 8-row tiles,
+        // 540 rows 137 -> 135 us against the sectioned queue; alone on a stream they time the same (profiles/r01_tuning.md)
+        tp.rows4 = (rows + 15) / 16 * 16;
+        tp.rows2 = 0;
     } else {
         // 16-row tiles for 85 % of the band, then 10 % in 8-row and the last 5 % in 4-row tiles (sweep in profiles/r01_tuning.md)
         tp.rows4 = (uint32_t)((uint64_t)rows * 850 / 1000) / 16 * 16;
@@ -878,10 +885,10 @@ hipError_t launch_primary(RenderArgs a, hipStream_t stream)
     a.tiles2 = tp.tiles2;
     a.tiles1 = tp.tiles1;
     const uint32_t n_tiles = a.tiles4 + a.tiles2 + a.tiles1;
-    // A small band (8-row tiles only: at most ~2 tiles per resident workgroup) is launched as a plain grid, one tile per workgroup: the
-    // queue has nothing to balance there, and workgroups that leave as they finish let the RCCL kernels of a multi-GPU step in
-    // (band pipeline with a real RCCL kernel per frame: 84 vs 87 us per step; 135-row band alone 0.044 vs 0.051 ms).
-    a.static_grid = a.tiles4 == 0 ? 1u : 0u;
+    // A launch of equal tiles (the two small-band plans above) goes out as a plain grid, one tile per workgroup: the queue has
+    // nothing to balance there, and workgroups that leave as they finish let the RCCL kernels of a multi-GPU step in (band pipeline
+    // with a real RCCL kernel per frame: 84 vs 87 us per step; 135-row band alone 0.044 vs 0.051 ms).
+    a.static_grid = (a.tiles4 == 0 || (a.tiles2 == 0 && a.tiles1 == 0)) ? 1u : 0u;
     const uint32_t grid = (a.static_grid || n_tiles < slots) ? n_tiles : slots;
     hipLaunchKernelGGL((render_kernel<kB, EMIT>), dim3(grid), dim3(kWaves * 64), 0, stream, a);
     return hipGetLastError();

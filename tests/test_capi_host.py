@@ -154,8 +154,10 @@ def test_tile_plan_covers_every_band_exactly_once():
         assert covered - rows < 16
     big = capi.tile_plan(3840, 2160, 1280)
     assert big["rows4"] == 1824 and big["rows2"] == 216 and big["tiles1"] == 60 * 30
-    band = capi.tile_plan(3840, 270, 1280)
-    assert band["rows4"] == 0 and band["tiles2"] == 60 * 34 and band["tiles1"] == 0
+    band = capi.tile_plan(3840, 270, 1024)   # the band of one of 8 ranks: 16-row tiles only
+    assert band["rows4"] == 272 and band["tiles4"] == 60 * 17 and band["tiles2"] == 0 and band["tiles1"] == 0
+    tiny = capi.tile_plan(3840, 135, 1024)   # well under one 16-row tile per workgroup slot: 8-row tiles only
+    assert tiny["rows4"] == 0 and tiny["tiles2"] == 60 * 17 and tiny["tiles1"] == 0
 
 
 def test_cpp_scene_generator_matches_python():
