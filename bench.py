@@ -84,15 +84,27 @@ def main():
     # Non-default streams: their handles are what the C ABI launches on, and the torch events below are recorded on them.
     # One rank, one stream: launches run back to back and the per-launch HIP-event durations are exclusive (clean roofline).
     # Several ranks: every rank renders only a band (270 rows at 8 GPUs), a launch too small to fill the chip on its own, so
-    # frames rotate over three slots = three streams: the render of frame k+1 overlaps the drain of frame k and the RCCL gather
-    # of frame k (measured on one GPU with 270-row bands: 103 -> 72 us per frame, tools/two_stream.py).  The streams are probed
-    # for real concurrency (pick_concurrent_streams).
-    slots = int(os.environ.get("BENCH_SLOTS", "3")) if use_dist else 1
+    # frames rotate over up to four slots = four streams: the render of frame k+1 overlaps the drain of frame k and the RCCL gather
+    # of frame k (measured on one GPU with 270-row bands: 103 -> 72 us per frame, tools/two_stream.py), and a gather may take up to
+    # three frame times before it holds up its slot (its kernel only gets workgroup slots as render workgroups leave).  The streams
+    # are probed for real concurrency (pick_concurrent_streams): as many slots as mutually concurrent streams, at most four.
+    slots = int(os.environ.get("BENCH_SLOTS", "4")) if use_dist else 1
+    if use_dist and os.environ.get("BENCH_GATHER") == "torch" and "BENCH_SLOTS" not in os.environ:
+        slots = 3  # the process group gathers on a stream of its own, a fifth stream on four hardware queues (91 vs 78 us per step)
     try:
         streams = pick_concurrent_streams(torch, dev, slots) if slots > 1 else [torch.cuda.Stream(dev)]
     except Exception as e:  # noqa: BLE001 - the probe is an optimisation; plain streams always work
         print("rank %d: stream probe failed (%s), using plain streams" % (rank, e), file=sys.stderr)
-        streams = [torch.cuda.Stream(dev) for _ in range(slots)]
+        streams = [torch.cuda.Stream(dev) for _ in range(min(slots, 3))]
+    if use_dist:
+        # every rank must rotate over the same number of slots (the slot picks the communicator): agree on the smallest number of
+        # mutually concurrent streams any rank found, but keep at least two frames in flight
+        agreed = torch.tensor([len(streams)], dtype=torch.int32, device=dev)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        slots = max(min(2, slots), min(slots, int(agreed[0])))
+        while len(streams) < slots:
+            streams.append(torch.cuda.Stream(dev))
+        streams = streams[:slots]
     torch.cuda.set_stream(streams[0])
     band_bufs = [torch.zeros((rows_max, w, 4), dtype=torch.uint8, device=dev) for _ in range(slots)]
     # BENCH_GATHER=rccl (default): grouped ncclSend/ncclRecv called directly (raytracing_amd.rccl_gather), rank 0 renders its band in
@@ -317,8 +329,7 @@ def pick_concurrent_streams(torch, dev, n, candidates=16, pool=None):
         if all(independent(a, c) and independent(c, a) for a in chosen):
             chosen.append(c)
     if len(chosen) < n:
-        print("only %d mutually concurrent streams found among %d candidates; reusing" % (len(chosen), candidates), file=sys.stderr)
-        chosen += [pool[i] for i in range(1, n - len(chosen) + 1)]
+        print("only %d mutually concurrent streams found among %d candidates" % (len(chosen), candidates), file=sys.stderr)
     return chosen[:n]
 
 
