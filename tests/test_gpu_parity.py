@@ -536,14 +536,21 @@ def test_many_launches_in_flight_on_several_streams(oracle):
     """Tile-queue counters are per stream: hundreds of band launches enqueued at once on three streams (the host far ahead of the GPU,
     as in the multi-GPU pipeline) all produce the exact band; a 17th distinct stream on one context is refused."""
     import torch
-    w, h = 1280, 720
-    objs, lights = scenegen.generate(w, h, 400, 3, seed=91)
+    w, h = 3840, 1000
+    objs, lights = scenegen.generate(w, h, 64, 3, seed=91)
     m = _cam(oracle, w, h)
     with capi.Context(0) as ctx:
         ctx.scene_upload(objs, lights)
         ref = ctx.render(m, w, h)
+        oref = oracle.render(objs, lights, m, w, h, row_step=8)
+        _assert_same(ref[::8], oref[::8], "reference frame of this test vs the oracle")
         streams = [torch.cuda.Stream() for _ in range(3)]
-        cuts = [(0, 90), (90, 400), (400, 720)]  # a small band (plain grid) and two with the queue
+        # the three tile plans of DESIGN.md 3: 8-row tiles on a plain grid, 16-row tiles on a plain grid, the sectioned queue
+        cuts = [(0, 100), (100, 400), (0, 1000)]
+        plans = [capi.tile_plan(w, b - a, 1024) for a, b in cuts]  # 1024 = 256 CUs x 4 resident workgroups of render_kernel
+        assert plans[0]["tiles4"] == 0 and plans[0]["tiles1"] == 0
+        assert plans[1]["tiles2"] == 0 and plans[1]["tiles1"] == 0
+        assert plans[2]["tiles4"] and plans[2]["tiles2"] and plans[2]["tiles1"]
         outs = [[torch.zeros((b - a, w, 4), dtype=torch.uint8, device="cuda") for (a, b) in cuts] for _ in streams]
         for k in range(240):
             s = k % 3
