@@ -99,9 +99,7 @@ def main():
     if use_dist:
         # every rank must rotate over the same number of slots (the slot picks the communicator): agree on the smallest number of
         # mutually concurrent streams any rank found, but keep at least two frames in flight
-        agreed = torch.tensor([len(streams)], dtype=torch.int32, device=dev)
-        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
-        slots = max(min(2, slots), min(slots, int(agreed[0])))
+        slots = bands.agree_slots(slots, len(streams), world, device=dev)
         while len(streams) < slots:
             streams.append(torch.cuda.Stream(dev))
         streams = streams[:slots]

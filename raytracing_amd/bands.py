@@ -21,6 +21,23 @@ def max_band_rows(h: int, world: int) -> int:
     return max(band_rows(h, world, r)[1] - band_rows(h, world, r)[0] for r in range(world))
 
 
+def agree_slots(wanted: int, found: int, world: int, group=None, device=None) -> int:
+    """Number of frames every rank keeps in flight.  All ranks must rotate over the SAME number of slots (the slot of a frame picks
+    its stream, its buffers and its communicator), but each rank may have found a different number of mutually concurrent streams:
+    take the smallest `found` of any rank, at most `wanted`, and never fewer than min(2, wanted) (two frames in flight still overlap
+    the gather with the next render, on shared queues if need be).  One rank: no collective."""
+    if wanted < 1:
+        raise ValueError("at least one slot")
+    lowest = found
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        t = torch.tensor([found], dtype=torch.int32, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+        lowest = int(t[0])
+    return max(min(2, wanted), min(wanted, lowest))
+
+
 def frame_gather_list(frame, h: int, world: int):
     """Rank 0: the gather's receive list as row views INTO `frame` ([h, w, ch], contiguous), so the collective itself
     assembles the frame and no copy follows.  Possible when every band has the same height (h % world == 0: the views are

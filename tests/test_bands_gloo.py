@@ -141,3 +141,26 @@ def test_gather_pipeline_single_rank_is_noop():
         assert pipe.begin(k) == k % 2
         pipe.submit(k, torch.zeros(1))
     pipe.drain()
+
+
+def _slots_worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    got = [bands.agree_slots(4, 4 if rank == 0 else 3, world),   # one rank found fewer concurrent streams
+           bands.agree_slots(4, 4, world),
+           bands.agree_slots(4, 1 if rank == 1 else 4, world),   # never below two frames in flight
+           bands.agree_slots(1, 4, world)]                       # unless one slot was asked for
+    np.save(os.path.join(outdir, f"slots{rank}.npy"), np.array(got))
+    dist.destroy_process_group()
+
+
+def test_ranks_agree_on_the_number_of_frame_slots(tmp_path):
+    """bench.py rotates frames over as many slots as concurrent streams exist; every rank must end up with the same number."""
+    assert bands.agree_slots(4, 3, 1) == 3 and bands.agree_slots(3, 16, 1) == 3 and bands.agree_slots(4, 0, 1) == 2
+    with pytest.raises(ValueError):
+        bands.agree_slots(0, 4, 1)
+    mp.spawn(_slots_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "slots0.npy"), np.load(tmp_path / "slots1.npy")
+    assert a.tolist() == b.tolist() == [3, 4, 2, 1]
