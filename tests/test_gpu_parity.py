@@ -284,7 +284,7 @@ def test_c3_full_size_general_path(gpu_ctx, oracle):
 def test_fuzz_scenes_cameras_modes(gpu_ctx, oracle):
     """60 random scenes: random sphere clouds (some around / behind the camera), mixed point/ambient lights (some inside spheres),
     non-default and non-perspective camera matrices (rotation, shear, row 2 not constant), depth 1-3, shadows on/off, RGB8/RGBA8,
-    every third scene with one or two planes (extension) mixed in.  RT_FUZZ_CASES / RT_FUZZ_SEED widen it for a soak run."""
+    every third scene with one or two planes (extension) mixed in, every twentieth on a frame of 0.3 - 13 Mpixel.  RT_FUZZ_CASES / RT_FUZZ_SEED widen it for a soak run."""
     rng = np.random.default_rng(int(os.environ.get("RT_FUZZ_SEED", "2024")))
     f = np.float32
     npix = nlit = 0
@@ -293,6 +293,8 @@ def test_fuzz_scenes_cameras_modes(gpu_ctx, oracle):
         n, nl = int(rng.integers(0, 180)), int(rng.integers(0, 6))
         if case % 10 == 9:  # several LDS chunks of spheres, more than 32 lights now and then
             n, nl = int(rng.integers(1000, 3000)), int(rng.integers(0, 40))
+        if case % 20 == 11:  # a large frame now and then: 16-row tiles on a plain grid, the sectioned queue, the chunked host copy
+            w, h, n = int(rng.choice([2560, 3840, 5000])), int(rng.integers(120, 2600)), min(n, 48)
         spread = f(rng.choice([3.0, 10.0, 40.0]))
         if case % 7 == 3:  # wild scales: tiny and huge scenes, radii from far below to far above the spacing
             spread = f(rng.choice([1e-3, 0.05, 700.0, 3e4]))
