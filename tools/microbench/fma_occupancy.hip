@@ -25,7 +25,10 @@ __global__ __launch_bounds__(256) void k_fma(float* __restrict__ out, const floa
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int i = 0; i < U; ++i) {
-            if (MODE == 3) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(x), "v"(y));
+            if (MODE == 5) asm volatile("v_fmac_f32_e32 %0, %1, %2" : "+v"(a[i]) : "v"(x), "v"(y));            // VOP2, 4-byte encoding
+            else if (MODE == 6) asm volatile("v_fma_f32 %0, %1, %2, -1.0" : "=v"(a[i]) : "v"(x), "v"(y));   // VOP3 with the inline constant, 8 bytes
+            else if (MODE == 7) asm volatile("v_mul_f32_e32 %0, %1, %2" : "=v"(a[i]) : "v"(x), "v"(y));     // VOP2
+            else if (MODE == 3) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(x), "v"(y));
             else if (MODE == 4) {   // the render loop's mix: 6 FMAs per max3
                 if (i % 7 == 6) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(a[i - 1]), "v"(a[i - 2]));
                 else asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(x), "v"(y));
@@ -88,6 +91,10 @@ int main()
     for (int w : {1, 2, 4, 8}) run("acc_wg64", k_fma<16, 0>, 16, w, 64, d_out, d_in, d_clk, ncu, total);
     for (int w : {2, 4, 8}) run("acc_prio3", k_fma<16, 2>, 16, w, 256, d_out, d_in, d_clk, ncu, total);
     for (int w : {1, 2, 4, 8}) run("max3", k_fma<16, 3>, 16, w, 256, d_out, d_in, d_clk, ncu, total);
+    for (int w : {2, 4, 8}) run("fmac_e32", k_fma<64, 5>, 64, w, 256, d_out, d_in, d_clk, ncu, total);
+    for (int w : {2, 4, 8}) run("fma_vop3_c", k_fma<64, 6>, 64, w, 256, d_out, d_in, d_clk, ncu, total);
+    for (int w : {2, 4, 8}) run("mul_e32", k_fma<64, 7>, 64, w, 256, d_out, d_in, d_clk, ncu, total);
+    for (int w : {2, 4, 8}) run("fma_vop3", k_fma<64, 0>, 64, w, 256, d_out, d_in, d_clk, ncu, total);
     for (int w : {1, 2, 3, 4, 8}) run("mix6:1", k_fma<56, 4>, 56, w, 256, d_out, d_in, d_clk, ncu, total);
     return 0;
 }
