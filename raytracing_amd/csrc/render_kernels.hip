@@ -835,9 +835,11 @@ TilePlan plan_tiles(uint32_t w, uint32_t rows, uint32_t slots)
         tp.rows4 = (rows + 15) / 16 * 16;
         tp.rows2 = 0;
     } else {
-        // 16-row tiles for 85 % of the band, then 10 % in 8-row and the last 5 % in 4-row tiles (sweep in profiles/r01_tuning.md)
-        tp.rows4 = (uint32_t)((uint64_t)rows * 850 / 1000) / 16 * 16;
-        tp.rows2 = (uint32_t)((uint64_t)rows * 100 / 1000) / 8 * 8;
+        // 16-row tiles for 98 % of the band, then 2 % in 8-row tiles and what rounding leaves over in 4-row tiles: the smaller shapes
+        // are less efficient per pixel (fewer FMAs per LDS read), so only the very end of the launch gets them (sweep in
+        // profiles/r01_tuning.md: C3 -1.2 %, C4 -2.8 % against the earlier 85 / 10 / 5 split; all 16-row tiles lose 2 %)
+        tp.rows4 = (uint32_t)((uint64_t)rows * 980 / 1000) / 16 * 16;
+        tp.rows2 = (uint32_t)((uint64_t)rows * 20 / 1000) / 8 * 8;
     }
     const uint32_t rest = rows > tp.rows4 + tp.rows2 ? rows - tp.rows4 - tp.rows2 : 0;
     tp.tiles4 = tp.strips * (tp.rows4 / 16);

@@ -153,7 +153,7 @@ def test_tile_plan_covers_every_band_exactly_once():
             assert p["rows4"] < rows
         assert covered - rows < 16
     big = capi.tile_plan(3840, 2160, 1280)
-    assert big["rows4"] == 1824 and big["rows2"] == 216 and big["tiles1"] == 60 * 30
+    assert big["rows4"] == 2112 and big["rows2"] == 40 and big["tiles1"] == 60 * 2
     band = capi.tile_plan(3840, 270, 1024)   # the band of one of 8 ranks: 16-row tiles only
     assert band["rows4"] == 272 and band["tiles4"] == 60 * 17 and band["tiles2"] == 0 and band["tiles1"] == 0
     tiny = capi.tile_plan(3840, 135, 1024)   # well under one 16-row tile per workgroup slot: 8-row tiles only
