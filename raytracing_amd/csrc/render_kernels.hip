@@ -827,11 +827,12 @@ TilePlan plan_tiles(uint32_t w, uint32_t rows, uint32_t slots)
         // (135 rows of a 4K frame alone on a stream: 0.050 vs 0.065 ms)
         tp.rows4 = 0;
         tp.rows2 = (rows + 7) / 8 * 8;
-    } else if (tiles16 < 3ull * slots) {
-        // up to three 16-row tiles per resident workgroup (the band of one of 4 or 8 ranks at 4K): 16-row tiles only, the efficient
-        // shape (one broadcast LDS read per 16 FMAs).  Such launches are what a multi-GPU host keeps several of in flight, and then
-        // the next launch covers the tail of this one: three streams, 270 rows 73.9 -> 68.3 us per frame against 8-row tiles,
-        // 540 rows 137 -> 135 us against the sectioned queue; alone on a stream they time the same (profiles/r01_tuning.md)
+    } else if (tiles16 < slots) {
+        // up to one 16-row tile per resident workgroup (the band of one of 8 ranks at 4K): 16-row tiles only, the efficient shape
+        // (one broadcast LDS read per 16 FMAs).  Such launches are what a multi-GPU host keeps several of in flight, and then the
+        // next launch covers the tail of this one: three streams, 270 rows 73.9 -> 68.3 us per frame against 8-row tiles; alone on
+        // a stream the two time the same.  From one tile per workgroup on the sectioned queue wins in that pipeline (540 rows:
+        // 140.6 against 143.2 us per step), although a plain grid would be 3 % faster alone on a stream (profiles/r01_tuning.md)
         tp.rows4 = (rows + 15) / 16 * 16;
         tp.rows2 = 0;
     } else {

@@ -548,7 +548,7 @@ def test_many_launches_in_flight_on_several_streams(oracle):
         _assert_same(ref[::8], oref[::8], "reference frame of this test vs the oracle")
         streams = [torch.cuda.Stream() for _ in range(3)]
         # the three tile plans of DESIGN.md 3: 8-row tiles on a plain grid, 16-row tiles on a plain grid, the sectioned queue
-        cuts = [(0, 100), (100, 400), (0, 1000)]
+        cuts = [(0, 100), (100, 350), (0, 1000)]
         plans = [capi.tile_plan(w, b - a, 1024) for a, b in cuts]  # 1024 = 256 CUs x 4 resident workgroups of render_kernel
         assert plans[0]["tiles4"] == 0 and plans[0]["tiles1"] == 0
         assert plans[1]["tiles2"] == 0 and plans[1]["tiles1"] == 0
