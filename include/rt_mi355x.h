@@ -112,9 +112,10 @@ int32_t rt_render_rows(rt_ctx* ctx, const float m[16], uint32_t w, uint32_t h, u
  * Device-resident variant: `d_out` (and nullable `d_hit_idx`) are DEVICE pointers on ctx's device; the kernels are enqueued on
  * `stream` (a hipStream_t; NULL => ctx's own stream) and the call returns without synchronising.  This is what a multi-GPU
  * host uses per rank before gathering the bands (RCCL) — and what bench.py times.
- * Launches of one ctx may overlap on different streams only if they are primary-only (depth == 1, no RT_SHADOWS); every stream
- * gets its own tile-queue counters, at most 16 distinct streams per ctx (RT_ERR_TOO_LARGE beyond).  Launches with depth > 1 or
- * RT_SHADOWS share the ctx's hit-record scratch and must be ordered one after the other (same stream, or events between streams).
+ * Primary-only launches (depth == 1, no RT_SHADOWS) of one ctx overlap freely on different streams: every stream in use gets its own
+ * tile-queue counters out of 16 slots, recycled as launches complete — any number of streams over the life of a ctx; with more than
+ * 16 streams busy AT ONCE the extra launches wait (stream-level) for a slot.  Launches with depth > 1 or RT_SHADOWS share the ctx's
+ * hit-record scratch: the library orders each one after the previous one (stream-level wait on an event), whatever their streams.
  */
 int32_t rt_render_rows_device(rt_ctx* ctx, const float m[16], uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t depth, uint32_t flags,
                               void* d_out, void* d_hit_idx, void* stream);

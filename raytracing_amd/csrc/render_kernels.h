@@ -59,6 +59,10 @@ TilePlan plan_tiles(uint32_t w, uint32_t rows, uint32_t slots);
 // Enqueue the render of args.[y0,y1) on `stream`. Returns the HIP status of the launch.
 hipError_t launch_render(const RenderArgs& args, hipStream_t stream);
 
+// Looks up, for the current device, what launch_render would otherwise look up on its first call (resident workgroup slots of the
+// persistent kernels).  Called once per context.
+hipError_t prime_launch_caches();
+
 // True if launch_render needs the rec_* scratch buffers for these args (depth > 1 or RT_SHADOWS).
 bool render_needs_records(const RenderArgs& args);
 

@@ -871,14 +871,26 @@ hipError_t resident_slots(Kernel kernel, uint32_t (&cache)[64], uint32_t& slots)
     return hipSuccess;
 }
 
+template <bool EMIT>
+hipError_t primary_slots(uint32_t& slots)
+{
+    static uint32_t cache[64] = {};
+    return resident_slots(render_kernel<kB, EMIT>, cache, slots);
+}
+
+hipError_t mask_slots_of_device(uint32_t& slots)
+{
+    static uint32_t cache[64] = {};
+    return resident_slots(shadow_mask_kernel<kMaskP, kShadowB, kShadowChunk>, cache, slots);
+}
+
 // Cut the band into the three tile sections of render_kernel and launch the persistent grid.
 template <bool EMIT>
 hipError_t launch_primary(RenderArgs a, hipStream_t stream)
 {
     if (!a.tile_ctr) return hipErrorInvalidValue;
-    static uint32_t cache[64] = {};
     uint32_t slots = 0;
-    hipError_t e = resident_slots(render_kernel<kB, EMIT>, cache, slots);
+    hipError_t e = primary_slots<EMIT>(slots);
     if (e != hipSuccess) return e;
     const TilePlan tp = plan_tiles(a.w, a.y1 - a.y0, slots);
     a.strips = tp.strips;
@@ -898,6 +910,17 @@ hipError_t launch_primary(RenderArgs a, hipStream_t stream)
 }
 }  // namespace
 
+// The resident-slot caches of the three persistent kernels for the current device (launch_primary / launch_render fill them on first
+// use otherwise): called at context creation so that no render call does set-up work.
+hipError_t prime_launch_caches()
+{
+    uint32_t slots = 0;
+    hipError_t e;
+    if ((e = primary_slots<false>(slots)) != hipSuccess) return e;
+    if ((e = primary_slots<true>(slots)) != hipSuccess) return e;
+    return mask_slots_of_device(slots);
+}
+
 hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
 {
     if (args.y1 <= args.y0 || args.w == 0) return hipSuccess;
@@ -914,17 +937,16 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
     // The record count lives on the device: the grids below are sized for the worst case (every pixel of the band hit) or persistent,
     // and workgroups with nothing to do leave at once — no host round trip between the launches.
     uint32_t mask_slots = 0;
-    if (shadows) {
-        static uint32_t cache[64] = {};
-        if ((e = resident_slots(shadow_mask_kernel<kMaskP, kShadowB, kShadowChunk>, cache, mask_slots)) != hipSuccess) return e;
-    }
+    if (shadows && (e = mask_slots_of_device(mask_slots)) != hipSuccess) return e;
     RenderArgs a = args;
     const uint32_t shade_wgs = (uint32_t)((npix + kWaves * 64 * kShadeP - 1) / (kWaves * 64 * kShadeP));
     const uint32_t occ_words = ((uint32_t)args.n_lights + 31u) / 32u;
     for (uint32_t it = 0; it < args.depth; ++it) {  // renderer.rs:46
         a.iter = it;
         if (shadows) {
-            if ((e = hipMemsetAsync(a.rec_occ, 0, (size_t)occ_words * a.rec_cap * sizeof(uint32_t), stream)) != hipSuccess) return e;
+            // only the words of this band's records (at most npix per plane), not the whole capacity of the scratch
+            for (uint32_t wd = 0; wd < occ_words; ++wd)
+                if ((e = hipMemsetAsync(a.rec_occ + (size_t)wd * a.rec_cap, 0, (size_t)npix * sizeof(uint32_t), stream)) != hipSuccess) return e;
             const uint64_t worst_tiles = (npix + kWaves * 64 * kMaskP - 1) / (kWaves * 64 * kMaskP) * (uint64_t)args.n_lights;
             if (worst_tiles >= (1ull << 32)) return hipErrorInvalidValue;  // the tile queue counts in 32 bits
             const uint32_t grid = worst_tiles < mask_slots ? (uint32_t)worst_tiles : mask_slots;

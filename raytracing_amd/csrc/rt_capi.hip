@@ -17,7 +17,7 @@ using namespace rtamd;
 struct rt_ctx {
     int device = -1;
     hipStream_t stream = nullptr, copy_stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr;  // start of the most recent launch (its end: ev_end)
     hipEvent_t ev_chunk[4] = {nullptr, nullptr, nullptr, nullptr};
     bool timed = false;
     std::string err;
@@ -45,11 +45,19 @@ struct rt_ctx {
     size_t rec_planes = 0;     // 4-byte planes of rec_capacity entries allocated after the 16-byte counter
     // tile-queue counters of the persistent primary kernel: a ring of slots (64 B apart), one per launch in flight
     uint32_t* d_tile_ctr = nullptr;
-    hipStream_t tile_slot_stream[16] = {};  // slot i belongs to this stream (launches of one stream execute in order and can share it)
+    hipStream_t tile_slot_stream[16] = {};  // slot i was last used by this stream (launches of one stream execute in order and can share it)
+    hipEvent_t tile_slot_ev[16] = {};       // recorded after the last launch that used slot i: the slot is free again once it has completed
+    uint64_t tile_slot_use[16] = {};        // use clock of that launch (least recently used slot is the one recycled)
+    uint64_t use_clock = 0;
     uint32_t tile_slots_used = 0;
+    hipEvent_t ev_end = nullptr;            // end of the most recent launch (one of tile_slot_ev), for rt_last_kernel_ms
+    // launches with depth > 1 or RT_SHADOWS share d_rec: each one waits (stream-level) for the previous one
+    hipEvent_t ev_general = nullptr;
+    bool general_pending = false;
+    hipStream_t general_stream = nullptr;
 };
 
-static constexpr uint32_t kTileSlots = 16;  // distinct streams one context can be rendered on
+static constexpr uint32_t kTileSlots = 16;  // launches of one context that can be in flight on different streams without waiting for each other
 
 static thread_local std::string g_create_err;
 
@@ -158,12 +166,25 @@ int32_t rt_ctx_create(rt_ctx** out, int32_t device_id)
     DeviceGuard guard(device_id);
     if ((e = guard.status) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev1)) != hipSuccess ||
+        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreateWithFlags(&c->ev_general, hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->ev_chunk[0], hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&c->ev_chunk[1], hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->ev_chunk[2], hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&c->ev_chunk[3], hipEventDisableTiming)) != hipSuccess ||
         (e = hipMalloc(reinterpret_cast<void**>(&c->d_tile_ctr), kTileSlots * 64)) != hipSuccess ||
         (e = hipMemset(c->d_tile_ctr, 0, kTileSlots * 64)) != hipSuccess) {
         int32_t rc = fail_hip(nullptr, e, "context setup");
+        rt_ctx_destroy(c);
+        return rc;
+    }
+    for (uint32_t i = 0; i < kTileSlots; ++i)
+        if ((e = hipEventCreate(&c->tile_slot_ev[i])) != hipSuccess) {
+            int32_t rc = fail_hip(nullptr, e, "context setup (slot events)");
+            rt_ctx_destroy(c);
+            return rc;
+        }
+    // What a launch would otherwise look up on first use (resident workgroup slots of the persistent kernels) is looked up here, so
+    // that no render call does set-up work.
+    if ((e = prime_launch_caches()) != hipSuccess) {
+        int32_t rc = fail_hip(nullptr, e, "context setup (launch caches)");
         rt_ctx_destroy(c);
         return rc;
     }
@@ -175,15 +196,16 @@ int32_t rt_ctx_destroy(rt_ctx* c)
 {
     if (!c) return RT_OK;
     DeviceGuard guard(c->device >= 0 ? c->device : 0);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    (void)hipDeviceSynchronize();  // launches of this context may still run on caller streams and read its buffers
     if (c->d_scene) (void)hipFree(c->d_scene);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_hit) (void)hipFree(c->d_hit);
     if (c->d_rec) (void)hipFree(c->d_rec);
     if (c->d_tile_ctr) (void)hipFree(c->d_tile_ctr);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_general) (void)hipEventDestroy(c->ev_general);
+    for (hipEvent_t e : c->tile_slot_ev)
+        if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_chunk)
         if (e) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
@@ -277,6 +299,37 @@ static int32_t check_render_args(rt_ctx* c, const float* m, uint32_t w, uint32_t
 
 }  // extern "C"
 
+// The tile-queue counters of a launch on `st`: kernels that can run concurrently must not share a queue, kernels of one stream run in
+// order and can.  Slots are recycled: same stream first, then a slot that was never used or whose last launch has completed, else the
+// least recently used slot — and `st` then waits (stream-level, the host does not block) for that slot's last launch.
+static int32_t take_tile_slot(rt_ctx* c, hipStream_t st, uint32_t& slot_out)
+{
+    uint32_t slot = kTileSlots;
+    for (uint32_t i = 0; i < c->tile_slots_used; ++i)
+        if (c->tile_slot_stream[i] == st) { slot = i; break; }
+    if (slot == kTileSlots) {
+        if (c->tile_slots_used < kTileSlots) {
+            slot = c->tile_slots_used++;
+        } else {
+            uint32_t lru = 0;
+            for (uint32_t i = 0; i < kTileSlots && slot == kTileSlots; ++i) {
+                const hipError_t q = hipEventQuery(c->tile_slot_ev[i]);
+                if (q == hipSuccess) slot = i;
+                else if (q != hipErrorNotReady) return fail_hip(c, q, "hipEventQuery(tile slot)");
+                if (c->tile_slot_use[i] < c->tile_slot_use[lru]) lru = i;
+            }
+            if (slot == kTileSlots) {
+                slot = lru;
+                RT_HIP(c, hipStreamWaitEvent(st, c->tile_slot_ev[slot], 0));
+            }
+        }
+        c->tile_slot_stream[slot] = st;
+    }
+    c->tile_slot_use[slot] = ++c->use_clock;
+    slot_out = slot;
+    return RT_OK;
+}
+
 // Enqueue the kernels of the band [y0, y1) on `st` (arguments already checked, ctx's device current).
 static int32_t enqueue_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t depth, uint32_t flags,
                             void* d_out, void* d_hit_idx, hipStream_t st)
@@ -289,48 +342,62 @@ static int32_t enqueue_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h
     a.out = static_cast<uint8_t*>(d_out);
     a.hit_idx = static_cast<int32_t*>(d_hit_idx);
     a.rec_count = nullptr; a.rec_pix = nullptr; a.rec_idx = nullptr; a.rec_t = nullptr;
-    {  // the tile-queue counters of this launch: one slot per stream, so kernels that can run concurrently never share a queue
-        uint32_t slot = 0;
-        while (slot < c->tile_slots_used && c->tile_slot_stream[slot] != st) ++slot;
-        if (slot == c->tile_slots_used) {
-            if (slot == kTileSlots) return fail(c, RT_ERR_TOO_LARGE, "a context can be rendered on at most 16 distinct streams");
-            c->tile_slot_stream[slot] = st;
-            ++c->tile_slots_used;
-        }
-        a.tile_ctr = c->d_tile_ctr + (size_t)slot * 16;
-    }
     a.strips = a.tiles4 = a.tiles2 = a.tiles1 = a.rows4 = a.rows2 = 0;
     a.rec_cap = 0; a.iter = 0; a.rec_state = nullptr; a.rec_occ = nullptr;
-    if (render_needs_records(a)) {
-        // scratch: [count (16 B) | pix | idx | t | 9 state planes (depth > 1) | occlusion planes (RT_SHADOWS)], planes of rec_capacity words
-        const size_t npix = (size_t)(y1 - y0) * w;
-        bool need_state = false;
-        uint32_t occ_words = 0;
-        render_scratch_layout(a, need_state, occ_words);
-        const size_t planes = 3 + (need_state ? 9 : 0) + occ_words;
-        if (npix > c->rec_capacity || planes > c->rec_planes) {  // grow (the previous launches that used it must be finished first)
-            const size_t cap = npix > c->rec_capacity ? npix : c->rec_capacity;
-            const size_t pl = planes > c->rec_planes ? planes : c->rec_planes;
-            RT_HIP(c, hipDeviceSynchronize());
-            if (c->d_rec) RT_HIP(c, hipFree(c->d_rec));
-            c->d_rec = nullptr;
-            c->rec_capacity = 0;
-            c->rec_planes = 0;
-            RT_HIP(c, hipMalloc(&c->d_rec, 16 + cap * pl * 4));
-            c->rec_capacity = cap;
-            c->rec_planes = pl;
+    const bool general = render_needs_records(a);
+    const size_t npix = (size_t)(y1 - y0) * w;
+    bool need_state = false;
+    uint32_t occ_words = 0;
+    render_scratch_layout(a, need_state, occ_words);
+    const size_t planes = 3 + (need_state ? 9 : 0) + occ_words;
+
+    uint32_t slot = 0;
+    char* rec_base = nullptr;
+    size_t rec_cap = 0;
+    {
+        const int32_t rc = take_tile_slot(c, st, slot);
+        if (rc != RT_OK) return rc;
+        a.tile_ctr = c->d_tile_ctr + (size_t)slot * 16;
+        if (general) {
+            // scratch: [count (16 B) | pix | idx | t | 9 state planes (depth > 1) | occlusion planes (RT_SHADOWS)], planes of rec_capacity words
+            if (npix > c->rec_capacity || planes > c->rec_planes) {  // grow (the previous launches that used it must be finished first)
+                const size_t cap = npix > c->rec_capacity ? npix : c->rec_capacity;
+                const size_t pl = planes > c->rec_planes ? planes : c->rec_planes;
+                RT_HIP(c, hipDeviceSynchronize());
+                if (c->d_rec) RT_HIP(c, hipFree(c->d_rec));
+                c->d_rec = nullptr;
+                c->rec_capacity = 0;
+                c->rec_planes = 0;
+                RT_HIP(c, hipMalloc(&c->d_rec, 16 + cap * pl * 4));
+                c->rec_capacity = cap;
+                c->rec_planes = pl;
+            }
+            rec_base = static_cast<char*>(c->d_rec);
+            rec_cap = c->rec_capacity;
+            // the records are one per context: a general launch on another stream than the previous one waits for it (stream-level)
+            if (c->general_pending && c->general_stream != st) RT_HIP(c, hipStreamWaitEvent(st, c->ev_general, 0));
         }
-        char* base = static_cast<char*>(c->d_rec);
-        const size_t plane = c->rec_capacity * 4;
-        a.rec_cap = (uint32_t)c->rec_capacity;
-        a.rec_count = reinterpret_cast<uint32_t*>(base);
-        a.rec_pix = reinterpret_cast<uint32_t*>(base + 16);
-        a.rec_idx = reinterpret_cast<int32_t*>(base + 16 + plane);
-        a.rec_t = reinterpret_cast<float*>(base + 16 + 2 * plane);
-        if (need_state) a.rec_state = reinterpret_cast<float*>(base + 16 + 3 * plane);
-        if (occ_words) a.rec_occ = reinterpret_cast<uint32_t*>(base + 16 + (3 + (need_state ? 9 : 0)) * plane);
+    }
+    if (general) {
+        const size_t plane = rec_cap * 4;
+        a.rec_cap = (uint32_t)rec_cap;
+        a.rec_count = reinterpret_cast<uint32_t*>(rec_base);
+        a.rec_pix = reinterpret_cast<uint32_t*>(rec_base + 16);
+        a.rec_idx = reinterpret_cast<int32_t*>(rec_base + 16 + plane);
+        a.rec_t = reinterpret_cast<float*>(rec_base + 16 + 2 * plane);
+        if (need_state) a.rec_state = reinterpret_cast<float*>(rec_base + 16 + 3 * plane);
+        if (occ_words) a.rec_occ = reinterpret_cast<uint32_t*>(rec_base + 16 + (3 + (need_state ? 9 : 0)) * plane);
     }
     RT_HIP(c, launch_render(a, st));
+    {
+        RT_HIP(c, hipEventRecord(c->tile_slot_ev[slot], st));
+        c->ev_end = c->tile_slot_ev[slot];
+        if (general) {
+            RT_HIP(c, hipEventRecord(c->ev_general, st));
+            c->general_pending = true;
+            c->general_stream = st;
+        }
+    }
     return RT_OK;
 }
 
@@ -347,7 +414,6 @@ int32_t rt_render_rows_device(rt_ctx* c, const float m[16], uint32_t w, uint32_t
     RT_HIP(c, hipEventRecord(c->ev0, st));
     rc = enqueue_rows(c, m, w, h, y0, y1, depth, flags, d_out, d_hit_idx, st);
     if (rc != RT_OK) return rc;
-    RT_HIP(c, hipEventRecord(c->ev1, st));
     c->timed = true;
     return RT_OK;
 }
@@ -399,7 +465,6 @@ int32_t rt_render_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h, uin
         if (hit_idx_host)
             RT_HIP(c, hipMemcpyAsync(hit_idx_host + off, static_cast<char*>(c->d_hit) + off * 4, (size_t)(r1 - r0) * w * 4, hipMemcpyDeviceToHost, c->copy_stream));
     }
-    RT_HIP(c, hipEventRecord(c->ev1, c->stream));
     c->timed = true;
     RT_HIP(c, hipStreamSynchronize(c->copy_stream));
     RT_HIP(c, hipStreamSynchronize(c->stream));
@@ -436,8 +501,8 @@ int32_t rt_last_kernel_ms(rt_ctx* c, float* ms)
     if (!c || !ms) return RT_ERR_INVALID;
     if (!c->timed) return fail(c, RT_ERR_INVALID, "no render has been enqueued on this context");
     RT_DEVICE(c);
-    RT_HIP(c, hipEventSynchronize(c->ev1));
-    RT_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    RT_HIP(c, hipEventSynchronize(c->ev_end));
+    RT_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev_end));
     return RT_OK;
 }
 
