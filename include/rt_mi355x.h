@@ -121,6 +121,21 @@ int32_t rt_render_rows_device(rt_ctx* ctx, const float m[16], uint32_t w, uint32
                               void* d_out, void* d_hit_idx, void* stream);
 
 /*
+ * NO COUNTERPART IN THE REFERENCE (it owns no device memory).  For callers that cannot allocate device memory while they render:
+ * code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same arguments and same result as
+ * rt_render_rows_device, but the call allocates and frees nothing: the kernels' scratch (tile-queue counters; for depth > 1 or
+ * RT_SHADOWS the dense hit records) lives in a fixed array of RT_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds from
+ * load to process exit.  Primary-only launches (depth == 1, no RT_SHADOWS) fit at any size; a general launch needs
+ * 272 + 4 * P * (y1 - y0) * w bytes, P = 3 + (depth > 1 ? 9 : 0) + (RT_SHADOWS ? ceil(n_lights / 32) : 0), and is refused with
+ * RT_ERR_TOO_LARGE beyond (e.g. shadows with <= 32 lights: 2.09 Mpixel per call; depth 2: 699 kpixel; cut larger frames into row bands).
+ * All calls on one GPU — of any context, of any thread — share that GPU's array: calls that overlap in time on one GPU race; order
+ * them (one stream, or events).  Does not update rt_last_kernel_ms.
+ */
+#define RT_NOALLOC_SCRATCH_BYTES (32u << 20)
+int32_t rt_render_rows_device_noalloc(rt_ctx* ctx, const float m[16], uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t depth,
+                                      uint32_t flags, void* d_out, void* d_hit_idx, void* stream);
+
+/*
  * Framebuffer::new (display.rs:46-61) allocates the pixel store the host entry points write into (a raw allocation turned into
  * an ImageBuffer with from_raw, display.rs:50-57).  Taking that store from rt_host_alloc (page-locked host memory, hipHostMalloc)
  * lets rt_render / rt_render_rows copy the frame at PCIe rate and overlap the copy of one row chunk with the render of the

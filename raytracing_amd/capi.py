@@ -22,6 +22,7 @@ RT_AMBIENT = 1
 RT_SHADOWS = 1
 RT_OUT_RGB8 = 2
 RT_SHADOW_EPS = 1.0e-3
+RT_NOALLOC_SCRATCH_BYTES = 32 << 20
 
 # RT_MI355X_LIB overrides the in-tree library (used to A/B kernel builds on the GPU box)
 LIB_PATH = os.environ.get("RT_MI355X_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "librt_mi355x.so")
@@ -29,7 +30,7 @@ LIB_PATH = os.environ.get("RT_MI355X_LIB") or os.path.join(os.path.dirname(os.pa
 EXPORTS = (
     "rt_version", "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_camera_transform", "rt_camera_default",
     "rt_scene_upload", "rt_render", "rt_render_rows", "rt_render_rows_device", "rt_last_kernel_ms",
-    "rt_debug_prepare_spheres", "rt_host_alloc", "rt_host_free", "rt_debug_tile_plan",
+    "rt_debug_prepare_spheres", "rt_host_alloc", "rt_host_free", "rt_debug_tile_plan", "rt_render_rows_device_noalloc",
 )
 
 _f32p = C.POINTER(C.c_float)
@@ -85,6 +86,7 @@ def load() -> C.CDLL:
     lib.rt_render.argtypes = [vp, _f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp]
     lib.rt_render_rows.argtypes = [vp, _f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
     lib.rt_render_rows_device.argtypes = [vp, _f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
+    lib.rt_render_rows_device_noalloc.argtypes = lib.rt_render_rows_device.argtypes
     lib.rt_last_kernel_ms.argtypes = [vp, _f32p]
     lib.rt_debug_prepare_spheres.argtypes = [C.POINTER(RtObjects), _f32p, _u8p]
     for name in EXPORTS:
@@ -257,6 +259,13 @@ class Context:
         self._check(self._lib.rt_render_rows_device(self._h, m.ctypes.data_as(_f32p), w, h, y0, y1, depth, flags,
                                                     C.c_void_p(d_out), C.c_void_p(d_hit_idx) if d_hit_idx else None,
                                                     C.c_void_p(stream) if stream else None))
+
+    def render_rows_device_noalloc(self, m, w: int, h: int, y0: int, y1: int, depth: int, flags: int, d_out: int, d_hit_idx: int = 0, stream: int = 0):
+        """rt_render_rows_device_noalloc: same result, scratch in the library's fixed per-GPU array, no allocation in the call."""
+        m = _f32(m)
+        self._check(self._lib.rt_render_rows_device_noalloc(self._h, m.ctypes.data_as(_f32p), w, h, y0, y1, depth, flags,
+                                                            C.c_void_p(d_out), C.c_void_p(d_hit_idx) if d_hit_idx else None,
+                                                            C.c_void_p(stream) if stream else None))
 
     def last_kernel_ms(self) -> float:
         ms = C.c_float()

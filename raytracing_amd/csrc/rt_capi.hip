@@ -55,6 +55,8 @@ struct rt_ctx {
     hipEvent_t ev_general = nullptr;
     bool general_pending = false;
     hipStream_t general_stream = nullptr;
+    // this device's copy of the file-scope scratch array of the allocation-free entry point (rt_render_rows_device_noalloc)
+    unsigned char* noalloc_scratch = nullptr;
 };
 
 static constexpr uint32_t kTileSlots = 16;  // launches of one context that can be in flight on different streams without waiting for each other
@@ -106,6 +108,31 @@ struct DeviceGuard {
 #define RT_DEVICE(ctx)                    \
     DeviceGuard device_guard_((ctx)->device); \
     RT_HIP(ctx, device_guard_.status)
+
+// ---- scratch of the allocation-free entry point (rt_render_rows_device_noalloc) -----------------------------------------------------
+// A fixed file-scope device array instead of hipMalloc'ed buffers: every GPU this library runs on holds its own copy at its own address
+// until the process ends.  In host code the NAME `scratch` is only a stand-in for HIP_SYMBOL(); the address a kernel, a memset or a copy
+// can use is the one hipGetSymbolAddress returns with that device current, looked up once per device (rt_ctx_create) and kept here.
+static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
+static constexpr size_t kNoAllocRecOffset = 256;  // [0, 64): tile-queue counters; [256, ...): hit-record count + planes
+
+static unsigned char* g_scratch_ptr[64] = {};  // per device; a benign race: concurrent callers store the same value
+
+static hipError_t noalloc_scratch_of_device(int device, unsigned char** out)  // `device` must be current
+{
+    *out = nullptr;
+    if (device < 0 || device >= 64) return hipErrorInvalidDevice;
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        g_scratch_ptr[device] = static_cast<unsigned char*>(p);
+    }
+    *out = g_scratch_ptr[device];
+    return hipSuccess;
+}
+
 
 extern "C" {
 
@@ -181,10 +208,10 @@ int32_t rt_ctx_create(rt_ctx** out, int32_t device_id)
             rt_ctx_destroy(c);
             return rc;
         }
-    // What a launch would otherwise look up on first use (resident workgroup slots of the persistent kernels) is looked up here, so
-    // that no render call does set-up work.
-    if ((e = prime_launch_caches()) != hipSuccess) {
-        int32_t rc = fail_hip(nullptr, e, "context setup (launch caches)");
+    // Everything a launch would otherwise look up on first use (resident workgroup slots of the persistent kernels, the device
+    // address of the allocation-free entry point's scratch array) is looked up here, so that no render call does set-up work.
+    if ((e = prime_launch_caches()) != hipSuccess || (e = noalloc_scratch_of_device(device_id, &c->noalloc_scratch)) != hipSuccess) {
+        int32_t rc = fail_hip(nullptr, e, "context setup (launch caches / scratch symbol)");
         rt_ctx_destroy(c);
         return rc;
     }
@@ -299,6 +326,10 @@ static int32_t check_render_args(rt_ctx* c, const float* m, uint32_t w, uint32_t
 
 }  // extern "C"
 
+// Where a launch finds its scratch (device memory beyond inputs and outputs): the context's own, grown on demand, or the fixed
+// file-scope array of the allocation-free entry point.
+enum class ScratchKind { kContext, kStatic };
+
 // The tile-queue counters of a launch on `st`: kernels that can run concurrently must not share a queue, kernels of one stream run in
 // order and can.  Slots are recycled: same stream first, then a slot that was never used or whose last launch has completed, else the
 // least recently used slot — and `st` then waits (stream-level, the host does not block) for that slot's last launch.
@@ -332,7 +363,7 @@ static int32_t take_tile_slot(rt_ctx* c, hipStream_t st, uint32_t& slot_out)
 
 // Enqueue the kernels of the band [y0, y1) on `st` (arguments already checked, ctx's device current).
 static int32_t enqueue_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t depth, uint32_t flags,
-                            void* d_out, void* d_hit_idx, hipStream_t st)
+                            void* d_out, void* d_hit_idx, hipStream_t st, ScratchKind kind = ScratchKind::kContext)
 {
     RenderArgs a;
     std::memcpy(a.m, m, sizeof(a.m));
@@ -354,7 +385,17 @@ static int32_t enqueue_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h
     uint32_t slot = 0;
     char* rec_base = nullptr;
     size_t rec_cap = 0;
-    {
+    if (kind == ScratchKind::kStatic) {
+        // [tile-queue counters (64 B) | pad to 256 | count (16 B) | planes of npix words]; everything that must start at zero is
+        // cleared on `st` (the counters here; the record count and the occlusion words by launch_render)
+        if (general && kNoAllocRecOffset + 16 + npix * planes * 4 > (size_t)RT_NOALLOC_SCRATCH_BYTES)
+            return fail(c, RT_ERR_TOO_LARGE, "rt_render_rows_device_noalloc: this band needs " + std::to_string(kNoAllocRecOffset + 16 + npix * planes * 4) +
+                                                 " bytes of hit-record scratch, the fixed array holds " + std::to_string((size_t)RT_NOALLOC_SCRATCH_BYTES));
+        a.tile_ctr = reinterpret_cast<uint32_t*>(c->noalloc_scratch);
+        RT_HIP(c, hipMemsetAsync(a.tile_ctr, 0, 64, st));
+        rec_base = reinterpret_cast<char*>(c->noalloc_scratch) + kNoAllocRecOffset;
+        rec_cap = npix;
+    } else {
         const int32_t rc = take_tile_slot(c, st, slot);
         if (rc != RT_OK) return rc;
         a.tile_ctr = c->d_tile_ctr + (size_t)slot * 16;
@@ -389,7 +430,7 @@ static int32_t enqueue_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h
         if (occ_words) a.rec_occ = reinterpret_cast<uint32_t*>(rec_base + 16 + (3 + (need_state ? 9 : 0)) * plane);
     }
     RT_HIP(c, launch_render(a, st));
-    {
+    if (kind == ScratchKind::kContext) {
         RT_HIP(c, hipEventRecord(c->tile_slot_ev[slot], st));
         c->ev_end = c->tile_slot_ev[slot];
         if (general) {
@@ -416,6 +457,18 @@ int32_t rt_render_rows_device(rt_ctx* c, const float m[16], uint32_t w, uint32_t
     if (rc != RT_OK) return rc;
     c->timed = true;
     return RT_OK;
+}
+
+int32_t rt_render_rows_device_noalloc(rt_ctx* c, const float m[16], uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t depth, uint32_t flags,
+                                      void* d_out, void* d_hit_idx, void* stream)
+{
+    int32_t rc = check_render_args(c, m, w, h, y0, y1, depth, flags);
+    if (rc != RT_OK) return rc;
+    if (y1 > y0 && !d_out) return fail(c, RT_ERR_INVALID, "output pointer is null");
+    if (!c->noalloc_scratch) return fail(c, RT_ERR_HIP, "the scratch array of this device was not resolved at rt_ctx_create");
+    RT_DEVICE(c);
+    hipStream_t st = stream ? static_cast<hipStream_t>(stream) : c->stream;
+    return enqueue_rows(c, m, w, h, y0, y1, depth, flags, d_out, d_hit_idx, st, ScratchKind::kStatic);
 }
 
 int32_t rt_render_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t depth, uint32_t flags,

@@ -59,6 +59,10 @@ extern "C" {
                           out_host: *mut u8, hit_idx_host: *mut i32) -> i32;
     pub fn rt_render_rows_device(ctx: *mut rt_ctx, m: *const f32, w: u32, h: u32, y0: u32, y1: u32, depth: u32, flags: u32,
                                  d_out: *mut c_void, d_hit_idx: *mut c_void, stream: *mut c_void) -> i32;
+    /// No counterpart in the reference: same as rt_render_rows_device but allocates nothing (scratch = a fixed per-GPU array of
+    /// RT_NOALLOC_SCRATCH_BYTES = 32 MiB); for callers that cannot call hipMalloc (graph capture, serving loops). RT_ERR_TOO_LARGE beyond.
+    pub fn rt_render_rows_device_noalloc(ctx: *mut rt_ctx, m: *const f32, w: u32, h: u32, y0: u32, y1: u32, depth: u32, flags: u32,
+                                 d_out: *mut c_void, d_hit_idx: *mut c_void, stream: *mut c_void) -> i32;
     pub fn rt_host_alloc(ctx: *mut rt_ctx, bytes: usize, out: *mut *mut c_void) -> i32;
     pub fn rt_host_free(ctx: *mut rt_ctx, host_ptr: *mut c_void) -> i32;
     pub fn rt_last_kernel_ms(ctx: *mut rt_ctx, ms: *mut f32) -> i32;
