@@ -6,7 +6,7 @@ A step = one pass of the hot path over one frame: every rank renders its row ban
 torch.distributed "nccl", double-buffered so the gather of frame k overlaps the render of frame k+1); with --gpus 1 no
 collective is issued.  Total work per step is fixed (one frame) => strong scaling.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3|C4|C5] [--no-cpu-baseline]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3|C4|C5] [--depth D] [--shadows] [--no-cpu-baseline]
   N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line (metric/value/roofline/cpu_baseline ...).  The oracle is used only for the cpu_baseline leg.
@@ -23,6 +23,8 @@ if ROOT not in sys.path:
 
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 FLOPS_PER_TEST = 6             # the hot loop executes three v_fma_f32 per (pixel, sphere) pair (render_kernels.h)
+FLOPS_PER_SHADOW_TEST = 6      # shadow_mask_kernel: the same 3-FMA filter per (shadow ray, sphere) with per-light constants
+FLOPS_PER_BOUNCE_TEST = 16     # trace_general: 3 sub + (2 FMA + 1 mul) + 3 FMA + 1 FMA per (bounce ray, sphere) = 10 VALU ops
 
 
 def main():
@@ -31,8 +33,12 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="C3", choices=["C3", "C4", "C5"])
+    ap.add_argument("--depth", type=int, default=1, help="renderer.rs:32 depth; > 1 runs the bounce path (general-ray kernels)")
+    ap.add_argument("--shadows", action="store_true", help="RT_SHADOWS extension (general-ray kernels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.depth < 1:
+        raise SystemExit("--depth must be >= 1")
 
     # Keep stdout for the ONE JSON line: native libraries (RCCL prints a version banner at communicator creation) write to
     # fd 1 directly, so fd 1 is pointed at stderr for the run and the JSON goes to a saved duplicate of the real stdout.
@@ -88,23 +94,22 @@ def main():
     # of frame k (measured on one GPU with 270-row bands: 103 -> 72 us per frame, tools/two_stream.py), and a gather may take up to
     # three frame times before it holds up its slot (its kernel only gets workgroup slots as render workgroups leave).  The streams
     # are probed for real concurrency (pick_concurrent_streams): as many slots as mutually concurrent streams, at most four.
+    general = args.depth > 1 or args.shadows
+    flags = capi.RT_SHADOWS if args.shadows else 0
     slots = int(os.environ.get("BENCH_SLOTS", "4")) if use_dist else 1
-    if use_dist and os.environ.get("BENCH_GATHER") == "torch" and "BENCH_SLOTS" not in os.environ:
-        slots = 3  # the process group gathers on a stream of its own, a fifth stream on four hardware queues (91 vs 78 us per step)
+    if general:
+        slots = min(slots, 2)  # general launches of one context are ordered by the library (shared hit records): two slots overlap the gather only
+    want_torch = use_dist and os.environ.get("BENCH_GATHER") == "torch"
+    found = 1
     try:
         streams = pick_concurrent_streams(torch, dev, slots) if slots > 1 else [torch.cuda.Stream(dev)]
+        found = len(streams)
     except Exception as e:  # noqa: BLE001 - the probe is an optimisation; plain streams always work
         print("rank %d: stream probe failed (%s), using plain streams" % (rank, e), file=sys.stderr)
         streams = [torch.cuda.Stream(dev) for _ in range(min(slots, 3))]
-    if use_dist:
-        # every rank must rotate over the same number of slots (the slot picks the communicator): agree on the smallest number of
-        # mutually concurrent streams any rank found, but keep at least two frames in flight
-        slots = bands.agree_slots(slots, len(streams), world, device=dev)
-        while len(streams) < slots:
-            streams.append(torch.cuda.Stream(dev))
-        streams = streams[:slots]
+        found = len(streams)
     torch.cuda.set_stream(streams[0])
-    band_bufs = [torch.zeros((rows_max, w, 4), dtype=torch.uint8, device=dev) for _ in range(slots)]
+    band_bufs = [torch.zeros((rows_max, w, 4), dtype=torch.uint8, device=dev) for _ in range(max(slots, 1))]
     # BENCH_GATHER=rccl (default): grouped ncclSend/ncclRecv called directly (raytracing_amd.rccl_gather), rank 0 renders its band in
     # place and receives the peers' bands straight into their rows of a [h, w, 4] frame (one frame per slot); everything of a frame
     # is enqueued on that frame's stream, so the host spends a few C calls per step.  BENCH_GATHER=torch: torch.distributed.gather
@@ -121,36 +126,48 @@ def main():
     pipe = None
     gather_lists = [None] * slots
     if gather_mode == "rccl":
-        # Self-check before anything is timed: every rank fills its band with (rank + 1), the bands are gathered, rank 0 looks at its
-        # frame.  Any failure on any rank (an RCCL error, a wrong byte) makes ALL ranks fall back to torch.distributed.gather.
-        ok = 1
-        try:
-            from raytracing_amd import rccl_gather
-            rccl = [rccl_gather.RcclBandGather(world, rank, local_rank) for _ in range(n_comms)]
-            for ci, comm in enumerate(rccl if world > 1 else []):
-                band_bufs[0].fill_(rank + 1 + ci)
-                if rank == 0:
-                    frames[0].zero_()
-                    frames[0][y0:y1].fill_(1 + ci)
-                torch.cuda.synchronize(dev)
-                comm.gather(h, w, streams[0].cuda_stream, band_ptr=0 if rank == 0 else band_bufs[0].data_ptr(), frame_ptr=frames[0].data_ptr() if rank == 0 else 0)
-                streams[0].synchronize()
-                if rank == 0:
-                    for r in range(world):
-                        a, b = bands.band_rows(h, world, r)
-                        if not bool((frames[0][a:b] == r + 1 + ci).all()):
-                            ok = 0
-            band_bufs[0].zero_()
-        except Exception as e:  # noqa: BLE001 - whatever went wrong, the proven path takes over
-            print("rank %d: direct RCCL gather unavailable (%s), falling back to torch.distributed.gather" % (rank, e), file=sys.stderr)
-            ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag[0]) == 0:
-            for comm in rccl or []:
-                comm.close()
-            rccl = None
+        # Collective-safe set-up (rccl_gather.create_agreed): library + unique ids locally, agreement, communicators, agreement, then a
+        # self-check before anything is timed — every rank fills its band with (rank + 1 + ci), the bands are gathered, rank 0 looks at
+        # its frame — and a last agreement.  ALL ranks get their communicators or ALL fall back to torch.distributed.gather.
+        from raytracing_amd import rccl_gather
+
+        def self_check(ci, comm):
+            if world == 1:
+                return True
+            band_bufs[0].fill_(rank + 1 + ci)
+            if rank == 0:
+                frames[0].zero_()
+                frames[0][y0:y1].fill_(1 + ci)
+            torch.cuda.synchronize(dev)
+            comm.gather(h, w, streams[0].cuda_stream, band_ptr=0 if rank == 0 else band_bufs[0].data_ptr(), frame_ptr=frames[0].data_ptr() if rank == 0 else 0)
+            streams[0].synchronize()
+            good = True
+            if rank == 0:
+                for r in range(world):
+                    a_, b_ = bands.band_rows(h, world, r)
+                    good = good and bool((frames[0][a_:b_] == r + 1 + ci).all())
+            return good
+
+        rccl = rccl_gather.create_agreed(world, rank, local_rank, n_comms, device=dev, self_check=self_check)
+        band_bufs[0].zero_()
+        if rccl is None:
             gather_mode = "torch"
+    if use_dist:
+        # every rank must rotate over the same number of slots (the slot picks the communicator): agree on the smallest number of
+        # mutually concurrent streams any rank found, but keep at least two frames in flight
+        wanted, usable, floor = slots, len(streams), 2
+        if gather_mode == "torch" and "BENCH_SLOTS" not in os.environ:
+            # torch.distributed.gather runs on the process group's OWN stream, tied to the frame streams by events in both directions
+            # (issue: pg stream waits for the frame stream; Work.wait(): frame stream waits for the pg stream).  That stream is one more
+            # client of the four hardware queues: keep frame streams + 1 within the number of streams the probe found to run
+            # concurrently, so that no frame stream shares a queue with it ("the hang on record").
+            wanted, usable, floor = min(slots, 3), found - 1, 1
+        slots = bands.agree_slots(wanted, usable, world, device=dev, floor=floor)
+        while len(streams) < slots:
+            streams.append(torch.cuda.Stream(dev))
+        streams = streams[:slots]
+        frames = frames[:slots] if rank == 0 else frames
+        n_comms = min(n_comms, slots)
     if gather_mode == "torch":
         if rank == 0:
             for s_ in range(slots):
@@ -171,7 +188,7 @@ def main():
                 pipe.begin(k)  # stream-level wait (on st) until the gather that last read band_bufs[s] is done
                 if ev is not None:
                     ev[0].record(st)
-                ctx.render_rows_device(m, w, h, y0, y1, 1, 0, band_bufs[s].data_ptr(), 0, st.cuda_stream)
+                ctx.render_rows_device(m, w, h, y0, y1, args.depth, flags, band_bufs[s].data_ptr(), 0, st.cuda_stream)
                 if ev is not None:
                     ev[1].record(st)
                 pipe.submit(k, band_bufs[s], gather_lists[s])  # the collective is ordered after st's render of this frame
@@ -186,7 +203,7 @@ def main():
         d_out = frames[s].data_ptr() + y0 * row_bytes if in_place else band_bufs[s].data_ptr()
         if ev is not None:
             ev[0].record(st)
-        ctx.render_rows_device(m, w, h, y0, y1, 1, 0, d_out, 0, st.cuda_stream)
+        ctx.render_rows_device(m, w, h, y0, y1, args.depth, flags, d_out, 0, st.cuda_stream)
         if ev is not None:
             ev[1].record(st)
 
@@ -211,13 +228,14 @@ def main():
     # is fixed (not wall-clock driven) so that every rank issues the same collectives.
     step()
     fence()
-    for _ in range(max(1, int(0.05 / (0.6e-3 / world)))):
+    for _ in range(max(1, int(0.05 / (0.6e-3 / world)) if not general else 8)):
         step()
     fence()
     for _ in range(args.warmup):
         step()
     fence()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    phase_ms = [0.0, 0.0, 0.0]
     fence()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -230,11 +248,28 @@ def main():
     elapsed = t1 - t0
     kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)  # HIP events on the launch stream
 
+    # General path: per-kernel durations of a launch come from the library's own HIP events between its kernels (rt_last_phase_ms):
+    # a few more steps after the timed region, one at a time, averaged.  Also the number of hit records (= rays the general kernels trace).
+    n_hits = None
+    if general:
+        n_ph = max(1, min(args.steps, 10))
+        for _ in range(n_ph):
+            ctx.render_rows_device(m, w, h, y0, y1, args.depth, flags, band_bufs[0].data_ptr(), 0, streams[0].cuda_stream)
+            p_ms = ctx.last_phase_ms()
+            for i_ in range(3):
+                phase_ms[i_] += p_ms[i_] / n_ph
+        hit = torch.empty(((y1 - y0), w), dtype=torch.int32, device=dev)
+        ctx.render_rows_device(m, w, h, y0, y1, 1, 0, band_bufs[0].data_ptr(), hit.data_ptr(), streams[0].cuda_stream)
+        streams[0].synchronize()
+        n_hits = int((hit >= 0).sum())
+        del hit
+
     # After the timed region, multi-rank runs only: the two halves of a step on their own (same streams, same rotation), so that the
     # JSON line says which side bounds the pipeline - the renders of the bands or the gather over the links.  Not part of `value`.
     diag = None
     if gather_mode == "rccl":
         n_diag = 120
+        fence()
         t_r0 = time.perf_counter()
         for k in range(n_diag):
             render_part(k % slots, streams[k % slots])
@@ -259,39 +294,77 @@ def main():
     if rank == 0:
         rays_per_step = w * h if rehearse_band <= 1 else (y1 - y0) * w
         value = rays_per_step * args.steps / elapsed_max
-        # roofline of the dominant kernel (this rank's launch): executed flops of the filter loop / its own duration
+        step_s = elapsed_max / args.steps
+        mode = "depth %d%s" % (args.depth, ", RT_SHADOWS (extension)" if args.shadows else "")
+        n_point = int((lights.kind == 0).sum()) if lights.kind is not None else lights.n
+        # roofline of the dominant kernel (this rank's launch): executed flops of its filter loop / its own duration
         my_tests = (y1 - y0) * w * objs.n
-        achieved = my_tests * FLOPS_PER_TEST / (kern_ms * 1e-3) / 1e12
+        kernels = [("render_kernel<primary>" if not general else "render_kernel<emit>", my_tests, FLOPS_PER_TEST, kern_ms if not general else phase_ms[0],
+                    "%d per (pixel,sphere) filter test x %d tests per launch" % (FLOPS_PER_TEST, my_tests))]
+        if general and args.shadows:
+            sh_tests = n_hits * n_point * objs.n * args.depth
+            kernels.append(("shadow_mask_kernel", sh_tests, FLOPS_PER_SHADOW_TEST, phase_ms[1],
+                            "%d per (shadow ray,sphere) filter test x %d hit records x %d point lights x %d spheres x %d iteration(s): an upper bound, "
+                            "the any-hit early-out skips tests and later iterations hold fewer live records" % (FLOPS_PER_SHADOW_TEST, n_hits, n_point, objs.n, args.depth)))
+        if general and args.depth > 1:
+            bo_tests = n_hits * objs.n * (args.depth - 1)
+            kernels.append(("shade_iter_kernel (shading + trace_general)", bo_tests, FLOPS_PER_BOUNCE_TEST, phase_ms[2],
+                            "%d per (bounce ray,sphere) filter test x %d hit records x %d spheres x %d bounce(s): an upper bound, rays that miss die" %
+                            (FLOPS_PER_BOUNCE_TEST, n_hits, objs.n, args.depth - 1)))
+        kernels.sort(key=lambda k_: -k_[3])
+        dom = kernels[0]
+        wall_based = slots > 1
+        if wall_based:
+            # several frames in flight: per-launch event durations overlap, so the fraction comes from the wall clock of the step (this
+            # rank's flops / step time) and cannot exceed what the device did in that time
+            dom_ms = step_s * 1e3
+            achieved = sum(k_[1] * k_[2] for k_ in kernels) / step_s / 1e12
+        else:
+            dom_ms = dom[3]
+            achieved = dom[1] * dom[2] / (dom_ms * 1e-3) / 1e12
+        metric = {"C3": "primary rays/sec at 4K, 1024 spheres (config C3)",
+                  "C4": "primary rays/sec at 8K, 8192 spheres (config C4)",
+                  "C5": "primary rays/sec at 4K, 4096 spheres, 32 lights (config C5)"}[args.config]
+        if general:
+            metric = metric.replace("primary rays/sec", "primary rays/sec [%s]" % mode)
         out = {
-            "metric": "primary rays/sec at 4K, 1024 spheres (config %s)" % args.config,
+            "metric": metric,
             "value": value,
             "unit": "rays/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed_max / args.steps * 1e3,
+            "ms_per_step": step_s * 1e3,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic (SCENE-GEN v1, PCG32 seed 42)",
-            "config": {"workload": "%s: %dx%d frame, %d spheres, %d point lights, depth 1, RGBA8 out" % (args.config, w, h, objs.n, lights.n),
-                       "parallelism": ("row bands x%d, RCCL gather to rank 0 (%s), %d frames in flight" % (world, ("grouped ncclSend/ncclRecv, %d communicators" % n_comms) if gather_mode == "rccl" else "torch.distributed.gather", slots)) if use_dist else "one rank, whole frame, one stream", "kernel": "render_kernel<primary>"},
+            "config": {"workload": "%s: %dx%d frame, %d spheres, %d point lights, %s, RGBA8 out" % (args.config, w, h, objs.n, lights.n, mode),
+                       "parallelism": ("row bands x%d, RCCL gather to rank 0 (%s), %d frames in flight" % (world, ("grouped ncclSend/ncclRecv, %d communicators" % n_comms) if gather_mode == "rccl" else "torch.distributed.gather", slots)) if use_dist else "one rank, whole frame, one stream", "kernel": dom[0]},
             "roofline": {"bound": "valu_fp32", "achieved": achieved, "peak": PEAK_FP32_VALU_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_VALU_TFLOPS, "traffic": None,
-                         "kernel_ms": kern_ms, "kernel_ms_max_over_ranks": kern_ms_max,
-                         "flops_counted": "%d per (pixel,sphere) filter test x %d tests per launch" % (FLOPS_PER_TEST, my_tests)},
+                         "kernel": dom[0] if not wall_based else "all kernels of this rank's step",
+                         "kernel_ms": dom_ms, "kernel_ms_max_over_ranks": kern_ms_max if not general else None,
+                         "duration_source": ("wall clock of the step (max over ranks): %d frames in flight on %d streams, per-launch event durations would overlap" % (slots, slots))
+                         if wall_based else ("HIP events on the launch stream around every timed launch" if not general else
+                                             "HIP events the library records between its kernels (rt_last_phase_ms), %d launches after the timed region" % max(1, min(args.steps, 10))),
+                         "flops_counted": dom[4] if not wall_based else "; ".join(k_[4] for k_ in kernels)},
         }
-        out["roofline"]["traffic"], out["roofline"]["traffic_note"] = pmc_traffic(args.config)
+        if general:
+            out["general_path"] = {"hit_records_per_launch": n_hits, "launch_ms_by_events": kern_ms,
+                                   "kernels": [{"kernel": k_[0], "ms": k_[3], "TFLOP/s": (k_[1] * k_[2] / (k_[3] * 1e-3) / 1e12) if k_[3] > 0 else None,
+                                                "frac": (k_[1] * k_[2] / (k_[3] * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS) if k_[3] > 0 else None,
+                                                "flops_counted": k_[4]} for k_ in kernels],
+                                   "rays_per_step": w * h + (n_hits * n_point * args.depth if args.shadows else 0) + n_hits * (args.depth - 1),
+                                   "note": "value counts primary rays only; rays_per_step adds the shadow and bounce rays (upper bounds, see flops_counted)"}
+        out["roofline"]["traffic"], out["roofline"]["traffic_note"] = pmc_traffic(args.config, args.depth, args.shadows, dom[0])
         if diag is not None:
             out["diagnostics"] = diag
         if rehearse_band > 1:
             out["rehearsal"] = "one rank rendering the band of 1/%d of the frame: host issue-rate probe, not a result" % rehearse_band
-        if slots > 1:
-            out["roofline"]["kernel_ms_note"] = ("%d frames in flight on %d streams: per-launch durations overlap, so achieved/frac here "
-                                                 "understate the steady-state rate; the exclusive figure is the one-rank run" % (slots, slots))
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(objs, lights, m, w, h)
+            out["cpu_baseline"] = cpu_baseline(objs, lights, m, w, h, args.depth, 1 if args.shadows else 0)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
 
     ctx.close()
@@ -331,38 +404,61 @@ def pick_concurrent_streams(torch, dev, n, candidates=16, pool=None):
     return chosen[:n]
 
 
-def pmc_traffic(config):
-    """HBM bytes per launch of the render kernel from the committed rocprofv3 PMC passes (profiles/r01_c3_pmc.txt: TCC_EA0_WRREQ x 64 B +
-    TCC_EA0_RDREQ x 64 B x 2, the gfx950 correction of MI355X_MICROARCH.md).  Counters cannot be read inside an unprofiled run, so this
-    is the value of the profiled run of the same command; None for other configs or if the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_c3_pmc.txt")
-    if config != "C3" or not os.path.exists(path):
-        return None, "no PMC pass committed for this config"
+def kernel_source_sha256():
+    """Identity of the kernels a PMC summary was taken with: SHA-256 over render_kernels.hip + render_kernels.h."""
+    import hashlib
+    hsh = hashlib.sha256()
+    for name in ("render_kernels.hip", "render_kernels.h"):
+        with open(os.path.join(ROOT, "raytracing_amd", "csrc", name), "rb") as f:
+            hsh.update(f.read())
+    return hsh.hexdigest()
+
+
+def pmc_traffic(config, depth=1, shadows=False, kernel="render_kernel<primary>"):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS command (profiles/r02_<tag>_pmc.txt,
+    written by tools/summarize_prof.py: TCC_EA0_WRREQ x 64 B + TCC_EA0_RDREQ x 64 B x 2, the gfx950 correction of MI355X_MICROARCH.md).
+    Counters cannot be read inside an unprofiled run, so this is the value of the profiled run of the same command — and only if
+    the summary was taken with the kernel sources this build comes from (its `kernel source sha256` line); otherwise None + a note."""
+    tag = config.lower() + ("_depth%d" % depth if depth > 1 else "") + ("_shadows" if shadows else "")
+    path = os.path.join(ROOT, "profiles", "r02_%s_pmc.txt" % tag)
+    if not os.path.exists(path):
+        return None, "no PMC pass committed for this command (%s)" % os.path.basename(path)
+    want = "render_kernel<16, false>" if kernel == "render_kernel<primary>" else ("render_kernel<16, true>" if kernel == "render_kernel<emit>" else kernel.split(" ")[0])
+    sha = None
     wr = rd = None
+    inside = False
     for line in open(path):
-        if line.startswith("HBM write bytes"):
+        if line.startswith("kernel source sha256"):
+            sha = line.rsplit("=", 1)[1].strip()
+        elif line.startswith("## "):
+            inside = want in line
+        elif inside and line.startswith("HBM write bytes"):
             wr = float(line.rsplit("=", 1)[1])
-        elif line.startswith("HBM read bytes"):
+        elif inside and line.startswith("HBM read bytes"):
             rd = float(line.rsplit("=", 1)[1])
+    if sha != kernel_source_sha256():
+        return None, "%s was taken with other kernel sources (sha256 %s...): stale, not reported" % (os.path.basename(path), (sha or "none")[:12])
     if wr is None or rd is None:
-        return None, "PMC summary has no HBM lines"
-    return wr + rd, "bytes per launch, from profiles/r01_c3_pmc.txt (separate --pmc passes of this command); algorithmic = W*H*4 = 33177600 written"
+        return None, "%s has no HBM lines for %s" % (os.path.basename(path), want)
+    return wr + rd, "bytes per launch of %s, from %s (separate --pmc passes of this command, same kernel sources)" % (want, os.path.relpath(path, ROOT))
 
 
-def cpu_baseline(objs, lights, m, w, h):
+def cpu_baseline(objs, lights, m, w, h, depth=1, flags=0):
     """The CPU oracle (C restatement of the reference, row-parallel like rayon) timed on this host on a bounded sample."""
     from tests import oracle_py
     orc = oracle_py.load()
     threads = min(orc.default_threads(), 16)
-    row_step = 2
+    row_step = 2 if objs.n <= 1024 else (8 if objs.n <= 4096 else 32)  # about 10-30 s of CPU work whatever the config
+    if flags:
+        row_step *= 4
     t0 = time.perf_counter()
-    orc.render(objs, lights, m, w, h, row_step=row_step, nthreads=threads)
+    orc.render(objs, lights, m, w, h, row_step=row_step, nthreads=threads, depth=depth, flags=flags)
     dt = time.perf_counter() - t0
     rows = (h + row_step - 1) // row_step
     # the same oracle on ONE thread, on a 16 x sparser sample (SURVEY 8d asks for both figures)
-    row_step1 = 32
+    row_step1 = 16 * row_step
     t0 = time.perf_counter()
-    orc.render(objs, lights, m, w, h, row_step=row_step1, nthreads=1)
+    orc.render(objs, lights, m, w, h, row_step=row_step1, nthreads=1, depth=depth, flags=flags)
     dt1 = time.perf_counter() - t0
     rows1 = (h + row_step1 - 1) // row_step1
     model = "unknown"

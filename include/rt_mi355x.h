@@ -149,6 +149,14 @@ int32_t rt_host_free(rt_ctx* ctx, void* host_ptr);
 int32_t rt_last_kernel_ms(rt_ctx* ctx, float* ms);
 
 /*
+ * Per-kernel GPU time (ms, hipEvent) of the most recent launch with depth > 1 or RT_SHADOWS on this ctx (the last row chunk, for the
+ * host-output entry points): ms[0] = primary kernel that emits the hit records, ms[1] = shadow_mask_kernel launches (RT_SHADOWS; with
+ * the clears of their occlusion words), ms[2] = shade_iter_kernel launches (shading + bounce trace), summed over the first 4
+ * iterations of renderer.rs:46.  RT_ERR_INVALID if the most recent launch was primary-only.  Synchronises on the launch's end.
+ */
+int32_t rt_last_phase_ms(rt_ctx* ctx, float ms[3]);
+
+/*
  * Host-only introspection of the scene preprocessing done by rt_scene_upload (no device needed; used by the CPU tests):
  * for n spheres writes filt[4*n] = (cx', cy', cz', 0) of the conservative primary-ray filter  d.c' - 1 >= 0  and
  * cls[n] = 1 if the sphere is filterable, 0 if it is always tested exactly.  See DESIGN.md "primary-ray filter".

@@ -21,11 +21,12 @@ def max_band_rows(h: int, world: int) -> int:
     return max(band_rows(h, world, r)[1] - band_rows(h, world, r)[0] for r in range(world))
 
 
-def agree_slots(wanted: int, found: int, world: int, group=None, device=None) -> int:
+def agree_slots(wanted: int, found: int, world: int, group=None, device=None, floor: int = 2) -> int:
     """Number of frames every rank keeps in flight.  All ranks must rotate over the SAME number of slots (the slot of a frame picks
     its stream, its buffers and its communicator), but each rank may have found a different number of mutually concurrent streams:
-    take the smallest `found` of any rank, at most `wanted`, and never fewer than min(2, wanted) (two frames in flight still overlap
-    the gather with the next render, on shared queues if need be).  One rank: no collective."""
+    take the smallest `found` of any rank, at most `wanted`, and never fewer than min(floor, wanted) (floor 2: two frames in flight
+    still overlap the gather with the next render, on shared queues if need be).  `wanted` and `floor` must be the same on every rank.
+    One rank: no collective."""
     if wanted < 1:
         raise ValueError("at least one slot")
     lowest = found
@@ -35,7 +36,7 @@ def agree_slots(wanted: int, found: int, world: int, group=None, device=None) ->
         t = torch.tensor([found], dtype=torch.int32, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
         lowest = int(t[0])
-    return max(min(2, wanted), min(wanted, lowest))
+    return max(min(floor, wanted), min(wanted, lowest))
 
 
 def frame_gather_list(frame, h: int, world: int):

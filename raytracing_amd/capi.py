@@ -30,7 +30,7 @@ LIB_PATH = os.environ.get("RT_MI355X_LIB") or os.path.join(os.path.dirname(os.pa
 EXPORTS = (
     "rt_version", "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_camera_transform", "rt_camera_default",
     "rt_scene_upload", "rt_render", "rt_render_rows", "rt_render_rows_device", "rt_last_kernel_ms",
-    "rt_debug_prepare_spheres", "rt_host_alloc", "rt_host_free", "rt_debug_tile_plan", "rt_render_rows_device_noalloc",
+    "rt_debug_prepare_spheres", "rt_host_alloc", "rt_host_free", "rt_debug_tile_plan", "rt_render_rows_device_noalloc", "rt_last_phase_ms",
 )
 
 _f32p = C.POINTER(C.c_float)
@@ -88,6 +88,7 @@ def load() -> C.CDLL:
     lib.rt_render_rows_device.argtypes = [vp, _f32p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp, vp]
     lib.rt_render_rows_device_noalloc.argtypes = lib.rt_render_rows_device.argtypes
     lib.rt_last_kernel_ms.argtypes = [vp, _f32p]
+    lib.rt_last_phase_ms.argtypes = [vp, _f32p]
     lib.rt_debug_prepare_spheres.argtypes = [C.POINTER(RtObjects), _f32p, _u8p]
     for name in EXPORTS:
         if name not in ("rt_version", "rt_last_error"):
@@ -266,6 +267,12 @@ class Context:
         self._check(self._lib.rt_render_rows_device_noalloc(self._h, m.ctypes.data_as(_f32p), w, h, y0, y1, depth, flags,
                                                             C.c_void_p(d_out), C.c_void_p(d_hit_idx) if d_hit_idx else None,
                                                             C.c_void_p(stream) if stream else None))
+
+    def last_phase_ms(self):
+        """(primary/emit, shadow mask, shade + bounce trace) kernel ms of the most recent general launch."""
+        ms = (C.c_float * 3)()
+        self._check(self._lib.rt_last_phase_ms(self._h, ms))
+        return float(ms[0]), float(ms[1]), float(ms[2])
 
     def last_kernel_ms(self) -> float:
         ms = C.c_float()

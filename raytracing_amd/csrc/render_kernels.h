@@ -56,8 +56,17 @@ struct TilePlan {
 };
 TilePlan plan_tiles(uint32_t w, uint32_t rows, uint32_t slots);
 
-// Enqueue the render of args.[y0,y1) on `stream`. Returns the HIP status of the launch.
-hipError_t launch_render(const RenderArgs& args, hipStream_t stream);
+// Optional timing of the phases of a general launch (depth > 1 or RT_SHADOWS): ev[0] before and ev[1] after the primary (emit) kernel,
+// then per iteration it < kPhaseIters of renderer.rs:46: ev[2 + 2 it] after shadow_mask_kernel (and the clear of its occlusion words),
+// ev[3 + 2 it] after shade_iter_kernel.  `iters` = iterations recorded.  Events are the caller's (timing enabled).
+constexpr uint32_t kPhaseIters = 4;
+struct PhaseEvents {
+    hipEvent_t ev[2 + 2 * kPhaseIters];
+    uint32_t iters;
+};
+
+// Enqueue the render of args.[y0,y1) on `stream`. Returns the HIP status of the launch.  `phases` (nullable) is filled for general launches.
+hipError_t launch_render(const RenderArgs& args, hipStream_t stream, PhaseEvents* phases = nullptr);
 
 // Looks up, for the current device, what launch_render would otherwise look up on its first call (resident workgroup slots of the
 // persistent kernels).  Called once per context.

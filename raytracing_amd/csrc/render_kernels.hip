@@ -921,8 +921,9 @@ hipError_t prime_launch_caches()
     return mask_slots_of_device(slots);
 }
 
-hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
+hipError_t launch_render(const RenderArgs& args, hipStream_t stream, PhaseEvents* phases)
 {
+    if (phases) phases->iters = 0;
     if (args.y1 <= args.y0 || args.w == 0) return hipSuccess;
     if (!is_general(args)) return launch_primary<false>(args, stream);
 
@@ -932,7 +933,9 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
     if ((args.depth > 1u && !args.rec_state) || (shadows && !args.rec_occ)) return hipErrorInvalidValue;
     hipError_t e = hipMemsetAsync(args.rec_count, 0, sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
+    if (phases && (e = hipEventRecord(phases->ev[0], stream)) != hipSuccess) return e;
     if ((e = launch_primary<true>(args, stream)) != hipSuccess) return e;
+    if (phases && (e = hipEventRecord(phases->ev[1], stream)) != hipSuccess) return e;
 
     // The record count lives on the device: the grids below are sized for the worst case (every pixel of the band hit) or persistent,
     // and workgroups with nothing to do leave at once — no host round trip between the launches.
@@ -953,8 +956,14 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream)
             hipLaunchKernelGGL((shadow_mask_kernel<kMaskP, kShadowB, kShadowChunk>), dim3(grid), dim3(kWaves * 64), 0, stream, a);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
+        const bool timed = phases && it < kPhaseIters;
+        if (timed && (e = hipEventRecord(phases->ev[2 + 2 * it], stream)) != hipSuccess) return e;
         hipLaunchKernelGGL((shade_iter_kernel<kShadeP>), dim3(shade_wgs), dim3(kWaves * 64), 0, stream, a);
         if ((e = hipGetLastError()) != hipSuccess) return e;
+        if (timed) {
+            if ((e = hipEventRecord(phases->ev[3 + 2 * it], stream)) != hipSuccess) return e;
+            phases->iters = it + 1;
+        }
     }
     return hipSuccess;
 }

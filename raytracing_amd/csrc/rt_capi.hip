@@ -53,6 +53,8 @@ struct rt_ctx {
     hipEvent_t ev_end = nullptr;            // end of the most recent launch (one of tile_slot_ev), for rt_last_kernel_ms
     // launches with depth > 1 or RT_SHADOWS share d_rec: each one waits (stream-level) for the previous one
     hipEvent_t ev_general = nullptr;
+    PhaseEvents phases = {};                // per-kernel timing of the most recent general launch (rt_last_phase_ms)
+    bool phases_valid = false;
     bool general_pending = false;
     hipStream_t general_stream = nullptr;
     // this device's copy of the file-scope scratch array of the allocation-free entry point (rt_render_rows_device_noalloc)
@@ -202,6 +204,12 @@ int32_t rt_ctx_create(rt_ctx** out, int32_t device_id)
         rt_ctx_destroy(c);
         return rc;
     }
+    for (hipEvent_t& pe : c->phases.ev)
+        if ((e = hipEventCreate(&pe)) != hipSuccess) {
+            int32_t rc = fail_hip(nullptr, e, "context setup (phase events)");
+            rt_ctx_destroy(c);
+            return rc;
+        }
     for (uint32_t i = 0; i < kTileSlots; ++i)
         if ((e = hipEventCreate(&c->tile_slot_ev[i])) != hipSuccess) {
             int32_t rc = fail_hip(nullptr, e, "context setup (slot events)");
@@ -232,6 +240,8 @@ int32_t rt_ctx_destroy(rt_ctx* c)
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev_general) (void)hipEventDestroy(c->ev_general);
     for (hipEvent_t e : c->tile_slot_ev)
+        if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->phases.ev)
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_chunk)
         if (e) (void)hipEventDestroy(e);
@@ -429,8 +439,11 @@ static int32_t enqueue_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h
         if (need_state) a.rec_state = reinterpret_cast<float*>(rec_base + 16 + 3 * plane);
         if (occ_words) a.rec_occ = reinterpret_cast<uint32_t*>(rec_base + 16 + (3 + (need_state ? 9 : 0)) * plane);
     }
-    RT_HIP(c, launch_render(a, st));
+    const bool time_phases = general && kind == ScratchKind::kContext;
+    if (time_phases) c->phases_valid = false;
+    RT_HIP(c, launch_render(a, st, time_phases ? &c->phases : nullptr));
     if (kind == ScratchKind::kContext) {
+        c->phases_valid = time_phases && c->phases.iters > 0;
         RT_HIP(c, hipEventRecord(c->tile_slot_ev[slot], st));
         c->ev_end = c->tile_slot_ev[slot];
         if (general) {
@@ -546,6 +559,25 @@ int32_t rt_host_free(rt_ctx* c, void* p)
     RT_DEVICE(c);
     RT_HIP(c, hipStreamSynchronize(c->copy_stream));  // no copy of this ctx may still target the block
     RT_HIP(c, hipHostFree(p));
+    return RT_OK;
+}
+
+int32_t rt_last_phase_ms(rt_ctx* c, float ms[3])
+{
+    if (!c || !ms) return RT_ERR_INVALID;
+    if (!c->phases_valid) return fail(c, RT_ERR_INVALID, "the most recent launch of this context was not a general one (depth > 1 or RT_SHADOWS)");
+    RT_DEVICE(c);
+    const PhaseEvents& p = c->phases;
+    RT_HIP(c, hipEventSynchronize(p.ev[1 + 2 * p.iters]));
+    float t = 0.0f;
+    RT_HIP(c, hipEventElapsedTime(&t, p.ev[0], p.ev[1]));
+    ms[0] = t; ms[1] = 0.0f; ms[2] = 0.0f;
+    for (uint32_t it = 0; it < p.iters; ++it) {
+        RT_HIP(c, hipEventElapsedTime(&t, p.ev[1 + 2 * it], p.ev[2 + 2 * it]));
+        ms[1] += t;
+        RT_HIP(c, hipEventElapsedTime(&t, p.ev[2 + 2 * it], p.ev[3 + 2 * it]));
+        ms[2] += t;
+    }
     return RT_OK;
 }
 

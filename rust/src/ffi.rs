@@ -65,6 +65,7 @@ extern "C" {
                                  d_out: *mut c_void, d_hit_idx: *mut c_void, stream: *mut c_void) -> i32;
     pub fn rt_host_alloc(ctx: *mut rt_ctx, bytes: usize, out: *mut *mut c_void) -> i32;
     pub fn rt_host_free(ctx: *mut rt_ctx, host_ptr: *mut c_void) -> i32;
+    pub fn rt_last_phase_ms(ctx: *mut rt_ctx, ms: *mut f32) -> i32; // ms[3]: emit, shadow mask, shade + bounce trace (general launches)
     pub fn rt_last_kernel_ms(ctx: *mut rt_ctx, ms: *mut f32) -> i32;
     pub fn rt_debug_tile_plan(w: u32, rows: u32, slots: u32, plan: *mut u32) -> i32;
     pub fn rt_debug_prepare_spheres(objects: *const rt_objects, filt: *mut f32, cls: *mut u8) -> i32;

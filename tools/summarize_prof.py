@@ -6,7 +6,9 @@ import sqlite3
 import sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
-dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r01_c3"
+dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r02_c3"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (kernel_source_sha256: ties the summary to the kernel sources it was taken with)
 os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
 
 lines = []
@@ -18,9 +20,17 @@ for name, calls, total, avg, pct in con.execute("select name,total_calls,total_d
     lines.append(f"\"{name[:140]}\",{calls},{total:.3f},{avg:.3f},{pct:.3f}")
 row = con.execute("select grid_size_x, grid_size_y, workgroup_size_x, lds_block_size, vgpr_count, accum_vgpr_count, sgpr_count, scratch_size "
                   "from rocpd_kernel_dispatch d join kernel_symbols k on 1=1 limit 0").fetchall() if False else None
+cmd = ""
+try:
+    cmd = open(os.path.join(src, "command.txt")).read().strip()
+except OSError:
+    pass
+lines.insert(0, "# command: " + cmd)
+lines.insert(1, "kernel source sha256 = " + bench.kernel_source_sha256())
 open(dst + "_kernel_stats.csv", "w").write("\n".join(lines) + "\n")
-
-out = ["# rocprofv3 --pmc passes, averages per dispatch, one block per rtamd kernel", ""]
+out = ["# rocprofv3 --pmc passes, averages per dispatch, one block per rtamd kernel", "# command: " + cmd,
+       "kernel source sha256 = " + bench.kernel_source_sha256(),
+       "# (VGPRs below is rocprofv3's vgpr_count column; the code object's allocation is in profiles/r02_kernel_resource_usage.txt)", ""]
 per_kernel = {}
 for f in sorted(glob.glob(os.path.join(src, "pmc_*", "c3_results.db"))):
     c = sqlite3.connect(f)
