@@ -1,5 +1,6 @@
 // examples/main.cpp — the reference's src/main.rs:34-56 written against the C++ host mirror: 100x100 frame, 2 spheres,
 // 1 point + 1 ambient light, render(1) -> result.png in the CWD.  Usage: ./main [width height [depth]]
+// RT_DEVICES=0,1,2,3 (or 0,0,0 for virtual bands on one GPU) renders through a multi-device context (rt_ctx_create_multi).
 #include <cstdio>
 #include <cstdlib>
 
@@ -20,7 +21,17 @@ int main(int argc, char** argv)
         std::vector<DynLight> lights;
         lights.push_back(Point::new_unsize(Vec3::ZERO(), Vec3(1.0f, 1.0f, 1.0f), 0.5f));  // main.rs:49
         lights.push_back(Ambient::new_unsize(0.1f * Vec3(1.0f, 1.0f, 1.0f)));              // main.rs:50
-        Renderer renderer(std::move(frame), std::move(elements), std::move(lights));
+        std::vector<int32_t> devices;
+        if (const char* env = std::getenv("RT_DEVICES"))
+            for (const char* p = env; *p;) {
+                char* end = nullptr;
+                const long d = std::strtol(p, &end, 10);
+                if (end == p) break;
+                devices.push_back((int32_t)d);
+                p = *end == ',' ? end + 1 : end;
+            }
+        if (devices.empty()) devices.push_back(0);
+        Renderer renderer(std::move(frame), std::move(elements), std::move(lights), devices);
         renderer.render(depth);  // main.rs:54
         size_t lit = 0;
         for (size_t i = 0; i + 2 < renderer.last_frame.size(); i += 3)

@@ -30,6 +30,7 @@ extern "C" {
 #define RT_ERR_HIP (-3)       /* a HIP runtime call failed; text in rt_last_error */
 #define RT_ERR_NO_SCENE (-4)  /* rt_render* before rt_scene_upload */
 #define RT_ERR_TOO_LARGE (-5) /* size beyond a documented limit */
+#define RT_ERR_RCCL (-6)      /* multi-device context: RCCL could not be loaded or an RCCL call failed; text in rt_last_error */
 
 /* object kinds — object/mod.rs:7-10 (trait Object); only Sphere exists in the reference (object/sphere.rs) */
 #define RT_SPHERE 0u
@@ -76,6 +77,21 @@ const char* rt_version(void);
 
 /* Replaces nothing in the reference (it owns no device state): creates the per-device context (stream, events, scene buffers). */
 int32_t rt_ctx_create(rt_ctx** out, int32_t device_id);
+/*
+ * The reference's one parallel axis is the rayon row split of display.rs:90-93; this is its multi-GPU form BEHIND the boundary
+ * (SURVEY 8b / 8e): ONE context over a list of devices, so that `Renderer::render` (renderer.rs:32-82) calling rt_render once uses
+ * them all.  Every entry of `device_ids` is one contiguous ROW BAND: entry g of n renders rows [y0 + rows*g/n, y0 + rows*(g+1)/n) of
+ * each rt_render* call with global row indices (display.rs:99) on device device_ids[g]; the scene is replicated by rt_scene_upload;
+ * band 0 is rendered in place in the frame on the ROOT device device_ids[0], the other bands into staging on their devices and
+ * gathered into their rows of the frame by one group of ncclSend/ncclRecv per call (RCCL over xGMI, loaded at run time: an RCCL
+ * already in the process, else $RT_RCCL_LIB, else librccl.so.1).  A device may appear more than once ("virtual bands": such a band
+ * travels through RCCL too, as a send of the device to itself — how the exchange is exercised on a one-GPU machine).
+ * The context works with every rt_* call except rt_render_rows_device_noalloc and rt_last_phase_ms; device pointers and streams
+ * passed to rt_render_rows_device belong to the root device.  One host thread issues all launches: at 8 devices a C3-sized frame is
+ * host-bound (about 10 us of launch calls per device); one process per GPU with rt_render_rows_device per rank (bench.py) is not.
+ * n_devices in [1, 64].  RT_ERR_RCCL if RCCL cannot be loaded or initialised (n_devices == 1 never needs it).
+ */
+int32_t rt_ctx_create_multi(rt_ctx** out, const int32_t* device_ids, int32_t n_devices);
 int32_t rt_ctx_destroy(rt_ctx* ctx);
 
 /* Text of the last error on this ctx (or of the last failed rt_ctx_create when ctx == NULL); never freed by the caller. */

@@ -13,6 +13,7 @@ RT_ERR_NO_DEVICE = -2
 RT_ERR_HIP = -3
 RT_ERR_NO_SCENE = -4
 RT_ERR_TOO_LARGE = -5
+RT_ERR_RCCL = -6
 
 RT_SPHERE = 0
 RT_PLANE = 1  # extension, no reference counterpart
@@ -30,7 +31,7 @@ LIB_PATH = os.environ.get("RT_MI355X_LIB") or os.path.join(os.path.dirname(os.pa
 EXPORTS = (
     "rt_version", "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_camera_transform", "rt_camera_default",
     "rt_scene_upload", "rt_render", "rt_render_rows", "rt_render_rows_device", "rt_last_kernel_ms",
-    "rt_debug_prepare_spheres", "rt_host_alloc", "rt_host_free", "rt_debug_tile_plan", "rt_render_rows_device_noalloc", "rt_last_phase_ms",
+    "rt_debug_prepare_spheres", "rt_host_alloc", "rt_host_free", "rt_debug_tile_plan", "rt_render_rows_device_noalloc", "rt_last_phase_ms", "rt_ctx_create_multi",
 )
 
 _f32p = C.POINTER(C.c_float)
@@ -76,6 +77,7 @@ def load() -> C.CDLL:
     lib.rt_last_error.restype = C.c_char_p
     lib.rt_last_error.argtypes = [vp]
     lib.rt_ctx_create.argtypes = [C.POINTER(vp), C.c_int32]
+    lib.rt_ctx_create_multi.argtypes = [C.POINTER(vp), C.POINTER(C.c_int32), C.c_int32]
     lib.rt_ctx_destroy.argtypes = [vp]
     lib.rt_camera_transform.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, _f32p]
     lib.rt_camera_default.argtypes = [_f32p, _f32p, _f32p]
@@ -187,13 +189,21 @@ def debug_prepare_spheres(objs: FlatObjects):
 class Context:
     """One rt_ctx == one device. Not thread-safe (mirrors `&mut self`, renderer.rs:32)."""
 
-    def __init__(self, device_id: int = 0):
+    def __init__(self, device_id: int = 0, device_ids: Optional[Sequence[int]] = None):
+        """Context(d): one device.  Context(device_ids=[...]): rt_ctx_create_multi — one row band per entry, gathered to device_ids[0]
+        inside the library (RCCL); a device may repeat (virtual bands)."""
         self._lib = load()
         self._h = C.c_void_p()
-        rc = self._lib.rt_ctx_create(C.byref(self._h), device_id)
+        if device_ids is not None:
+            ids = (C.c_int32 * len(device_ids))(*[int(d) for d in device_ids])
+            rc = self._lib.rt_ctx_create_multi(C.byref(self._h), ids, len(device_ids))
+            device_id = int(device_ids[0]) if len(device_ids) else -1
+        else:
+            rc = self._lib.rt_ctx_create(C.byref(self._h), device_id)
         if rc != RT_OK:
             raise RtError(rc, (self._lib.rt_last_error(None) or b"").decode())
         self.device_id = device_id
+        self.device_ids = list(device_ids) if device_ids is not None else [device_id]
         self._pinned = {}
 
     def _check(self, rc: int):

@@ -10,6 +10,7 @@
 
 #include "render_kernels.h"
 #include "rt_mi355x.h"
+#include "rt_multi.h"
 #include "scene_prep.h"
 
 using namespace rtamd;
@@ -59,6 +60,15 @@ struct rt_ctx {
     hipStream_t general_stream = nullptr;
     // this device's copy of the file-scope scratch array of the allocation-free entry point (rt_render_rows_device_noalloc)
     unsigned char* noalloc_scratch = nullptr;
+    // staging of the bands this context renders as a PART of a multi-device context: [pixels | hit indices] per band
+    void* d_band = nullptr;
+    size_t d_band_bytes = 0;
+    // ---- multi-device context (rt_ctx_create_multi): owns no scene or scratch of its own, only the parts, the band list and two events
+    bool multi = false;
+    std::vector<rt_ctx*> parts;   // one single-device context per DISTINCT device of the list; parts[0] is on the root device
+    std::vector<int> band_part;   // per band (= entry of the device list): index into parts
+    BandGather gather;            // RCCL communicators over the parts (only when there is more than one band)
+    hipEvent_t ev_multi_end = nullptr;
 };
 
 static constexpr uint32_t kTileSlots = 16;  // launches of one context that can be in flight on different streams without waiting for each other
@@ -227,15 +237,76 @@ int32_t rt_ctx_create(rt_ctx** out, int32_t device_id)
     return RT_OK;
 }
 
+int32_t rt_ctx_create_multi(rt_ctx** out, const int32_t* device_ids, int32_t n_devices)
+{
+    if (!out) return fail(nullptr, RT_ERR_INVALID, "rt_ctx_create_multi: out is null");
+    *out = nullptr;
+    if (!device_ids || n_devices < 1 || n_devices > 64) return fail(nullptr, RT_ERR_INVALID, "rt_ctx_create_multi: 1 to 64 bands (entries of the device list)");
+    rt_ctx* c = new (std::nothrow) rt_ctx();
+    if (!c) return fail(nullptr, RT_ERR_HIP, "out of host memory");
+    c->multi = true;
+    c->device = device_ids[0];
+    std::vector<int> devices;  // distinct, in order of first appearance: devices[0] is the root
+    for (int32_t g = 0; g < n_devices; ++g) {
+        size_t p = 0;
+        while (p < devices.size() && devices[p] != device_ids[g]) ++p;
+        if (p == devices.size()) {
+            rt_ctx* part = nullptr;
+            const int32_t rc = rt_ctx_create(&part, device_ids[g]);  // error text is already in g_create_err
+            if (rc != RT_OK) {
+                rt_ctx_destroy(c);
+                return rc;
+            }
+            devices.push_back(device_ids[g]);
+            c->parts.push_back(part);
+        }
+        c->band_part.push_back((int)p);
+    }
+    {
+        DeviceGuard guard(c->device);
+        hipError_t e;
+        if ((e = guard.status) != hipSuccess || (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev_multi_end)) != hipSuccess) {
+            const int32_t rc = fail_hip(nullptr, e, "multi-device context setup");
+            rt_ctx_destroy(c);
+            return rc;
+        }
+    }
+    if (n_devices > 1) {  // one band needs no exchange at all: RCCL is not even loaded
+        const std::string msg = c->gather.init(devices);
+        if (!msg.empty()) {
+            rt_ctx_destroy(c);
+            return fail(nullptr, RT_ERR_RCCL, "rt_ctx_create_multi: " + msg);
+        }
+    }
+    *out = c;
+    return RT_OK;
+}
+
 int32_t rt_ctx_destroy(rt_ctx* c)
 {
     if (!c) return RT_OK;
+    if (c->multi) {
+        for (rt_ctx* p : c->parts) {  // every launch and transfer has finished before the communicators go
+            DeviceGuard g(p->device);
+            (void)hipDeviceSynchronize();
+        }
+        c->gather.destroy();
+        {
+            DeviceGuard g(c->device >= 0 ? c->device : 0);
+            if (c->ev0) (void)hipEventDestroy(c->ev0);
+            if (c->ev_multi_end) (void)hipEventDestroy(c->ev_multi_end);
+        }
+        for (rt_ctx* p : c->parts) (void)rt_ctx_destroy(p);
+        delete c;
+        return RT_OK;
+    }
     DeviceGuard guard(c->device >= 0 ? c->device : 0);
     (void)hipDeviceSynchronize();  // launches of this context may still run on caller streams and read its buffers
     if (c->d_scene) (void)hipFree(c->d_scene);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_hit) (void)hipFree(c->d_hit);
     if (c->d_rec) (void)hipFree(c->d_rec);
+    if (c->d_band) (void)hipFree(c->d_band);
     if (c->d_tile_ctr) (void)hipFree(c->d_tile_ctr);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev_general) (void)hipEventDestroy(c->ev_general);
@@ -254,6 +325,15 @@ int32_t rt_ctx_destroy(rt_ctx* c)
 int32_t rt_scene_upload(rt_ctx* c, const rt_objects* o, const rt_lights* l)
 {
     if (!c) return RT_ERR_INVALID;
+    if (c->multi) {  // the scene is replicated: every device keeps its own copy (at most a few MiB)
+        c->have_scene = false;
+        for (rt_ctx* p : c->parts) {
+            const int32_t rc = rt_scene_upload(p, o, l);
+            if (rc != RT_OK) return fail(c, rc, p->err);
+        }
+        c->have_scene = true;
+        return RT_OK;
+    }
     PreparedScene ps;
     std::string msg = prepare_scene(o, l, ps);
     if (!msg.empty()) return fail(c, RT_ERR_INVALID, "rt_scene_upload: " + msg);
@@ -455,6 +535,66 @@ static int32_t enqueue_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h
     return RT_OK;
 }
 
+// Multi-device context: cut [y0, y1) into one contiguous band per entry of the device list (global row indices in the ray formula,
+// display.rs:99), render band 0 in place in the caller's frame on the root device and every other band into its part's staging, on
+// that part's own stream; then ONE RCCL group gathers the staged bands into their rows of the frame (rt_multi.cpp).  `st_root` is the
+// stream the caller waits on: the receives are enqueued on it, so "st_root idle" means the whole frame has landed.
+static int32_t multi_enqueue(rt_ctx* c, const float m[16], uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t depth, uint32_t flags,
+                             void* d_out, void* d_hit_idx, hipStream_t st_root)
+{
+    const uint32_t G = (uint32_t)c->band_part.size(), rows = y1 - y0;
+    const size_t bpp = (flags & RT_OUT_RGB8) ? 3 : 4;
+    struct Band { uint32_t b0, b1; int part; size_t off; };
+    std::vector<Band> bands(G);
+    std::vector<size_t> need(c->parts.size(), 0);
+    for (uint32_t g = 0; g < G; ++g) {
+        Band& b = bands[g];
+        b.b0 = y0 + (uint32_t)((uint64_t)rows * g / G);
+        b.b1 = y0 + (uint32_t)((uint64_t)rows * (g + 1) / G);
+        b.part = c->band_part[g];
+        b.off = 0;
+        if (g > 0) {
+            b.off = need[(size_t)b.part];
+            need[(size_t)b.part] += ((size_t)(b.b1 - b.b0) * w * (bpp + (d_hit_idx ? 4 : 0)) + 255) / 256 * 256;
+        }
+    }
+    for (size_t p = 0; p < c->parts.size(); ++p) {
+        rt_ctx* part = c->parts[p];
+        if (need[p] <= part->d_band_bytes) continue;
+        DeviceGuard guard(part->device);
+        RT_HIP(c, guard.status);
+        RT_HIP(c, hipDeviceSynchronize());  // earlier frames may still be sending out of the old staging
+        if (part->d_band) RT_HIP(c, hipFree(part->d_band));
+        part->d_band = nullptr;
+        part->d_band_bytes = 0;
+        RT_HIP(c, hipMalloc(&part->d_band, need[p]));
+        part->d_band_bytes = need[p];
+    }
+    std::vector<BandXfer> xfers;
+    for (uint32_t g = 0; g < G; ++g) {
+        const Band& b = bands[g];
+        if (b.b1 == b.b0) continue;
+        rt_ctx* part = c->parts[(size_t)b.part];
+        const size_t npix = (size_t)(b.b1 - b.b0) * w, dst_off = (size_t)(b.b0 - y0) * w;
+        hipStream_t st = b.part == 0 ? st_root : part->stream;
+        char* out = g == 0 ? static_cast<char*>(d_out) : static_cast<char*>(part->d_band) + b.off;
+        char* hit = !d_hit_idx ? nullptr : (g == 0 ? static_cast<char*>(d_hit_idx) : out + npix * bpp);
+        {
+            DeviceGuard guard(part->device);
+            RT_HIP(c, guard.status);
+            const int32_t rc = enqueue_rows(part, m, w, h, b.b0, b.b1, depth, flags, out, hit, st);
+            if (rc != RT_OK) return fail(c, rc, part->err);
+        }
+        if (g > 0) {
+            xfers.push_back(BandXfer{b.part, out, static_cast<char*>(d_out) + dst_off * bpp, npix * bpp, st});
+            if (hit) xfers.push_back(BandXfer{b.part, hit, static_cast<char*>(d_hit_idx) + dst_off * 4, npix * 4, st});
+        }
+    }
+    const std::string msg = c->gather.gather(xfers, st_root);
+    if (!msg.empty()) return fail(c, RT_ERR_RCCL, "band gather: " + msg);
+    return RT_OK;
+}
+
 extern "C" {
 
 int32_t rt_render_rows_device(rt_ctx* c, const float m[16], uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t depth, uint32_t flags,
@@ -464,6 +604,15 @@ int32_t rt_render_rows_device(rt_ctx* c, const float m[16], uint32_t w, uint32_t
     if (rc != RT_OK) return rc;
     if (y1 > y0 && !d_out) return fail(c, RT_ERR_INVALID, "output pointer is null");
     RT_DEVICE(c);
+    if (c->multi) {
+        hipStream_t st = stream ? static_cast<hipStream_t>(stream) : c->parts[0]->stream;
+        RT_HIP(c, hipEventRecord(c->ev0, st));
+        if (y1 > y0 && (rc = multi_enqueue(c, m, w, h, y0, y1, depth, flags, d_out, d_hit_idx, st)) != RT_OK) return rc;
+        RT_HIP(c, hipEventRecord(c->ev_multi_end, st));
+        c->ev_end = c->ev_multi_end;
+        c->timed = true;
+        return RT_OK;
+    }
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : c->stream;
     RT_HIP(c, hipEventRecord(c->ev0, st));
     rc = enqueue_rows(c, m, w, h, y0, y1, depth, flags, d_out, d_hit_idx, st);
@@ -478,6 +627,7 @@ int32_t rt_render_rows_device_noalloc(rt_ctx* c, const float m[16], uint32_t w, 
     int32_t rc = check_render_args(c, m, w, h, y0, y1, depth, flags);
     if (rc != RT_OK) return rc;
     if (y1 > y0 && !d_out) return fail(c, RT_ERR_INVALID, "output pointer is null");
+    if (c->multi) return fail(c, RT_ERR_INVALID, "rt_render_rows_device_noalloc works on single-device contexts (a multi-device context stages bands in allocated buffers)");
     if (!c->noalloc_scratch) return fail(c, RT_ERR_HIP, "the scratch array of this device was not resolved at rt_ctx_create");
     RT_DEVICE(c);
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : c->stream;
@@ -494,6 +644,37 @@ int32_t rt_render_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h, uin
     RT_DEVICE(c);
     const size_t npix = (size_t)(y1 - y0) * w;
     const size_t bytes = npix * ((flags & RT_OUT_RGB8) ? 3 : 4);
+    if (c->multi) {
+        // the frame is assembled on the root device (bands rendered on every device of the list, gathered over RCCL), then copied out
+        rt_ctx* root = c->parts[0];
+        const size_t total = (bytes + 255) / 256 * 256 + (hit_idx_host ? npix * 4 : 0);
+        if (total > root->d_out_bytes) {
+            RT_HIP(c, hipStreamSynchronize(root->stream));
+            if (root->d_out) RT_HIP(c, hipFree(root->d_out));
+            root->d_out = nullptr;
+            root->d_out_bytes = 0;
+            RT_HIP(c, hipMalloc(&root->d_out, total));
+            root->d_out_bytes = total;
+        }
+        char* d_pix = static_cast<char*>(root->d_out);
+        char* d_hit = hit_idx_host ? d_pix + (bytes + 255) / 256 * 256 : nullptr;
+        RT_HIP(c, hipEventRecord(c->ev0, root->stream));
+        rc = multi_enqueue(c, m, w, h, y0, y1, depth, flags, d_pix, d_hit, root->stream);
+        if (rc != RT_OK) {
+            for (rt_ctx* p : c->parts) {  // nothing of this call may still be in flight when the caller gets its buffers back
+                DeviceGuard g(p->device);
+                (void)hipDeviceSynchronize();
+            }
+            return rc;
+        }
+        RT_HIP(c, hipEventRecord(c->ev_multi_end, root->stream));
+        c->ev_end = c->ev_multi_end;
+        c->timed = true;
+        RT_HIP(c, hipMemcpyAsync(out_host, d_pix, bytes, hipMemcpyDeviceToHost, root->stream));
+        if (hit_idx_host) RT_HIP(c, hipMemcpyAsync(hit_idx_host, d_hit, npix * 4, hipMemcpyDeviceToHost, root->stream));
+        RT_HIP(c, hipStreamSynchronize(root->stream));
+        return RT_OK;
+    }
     if (bytes > c->d_out_bytes) {
         if (c->d_out) RT_HIP(c, hipFree(c->d_out));
         c->d_out = nullptr;
@@ -547,7 +728,7 @@ int32_t rt_host_alloc(rt_ctx* c, size_t bytes, void** out)
     if (!c) return RT_ERR_INVALID;
     if (!out || bytes == 0) return fail(c, RT_ERR_INVALID, "rt_host_alloc: empty request");
     *out = nullptr;
-    RT_DEVICE(c);
+    RT_DEVICE(c);  // (a multi-device context allocates with its root device current)
     RT_HIP(c, hipHostMalloc(out, bytes, hipHostMallocDefault));
     return RT_OK;
 }
@@ -557,7 +738,8 @@ int32_t rt_host_free(rt_ctx* c, void* p)
     if (!c) return RT_ERR_INVALID;
     if (!p) return RT_OK;
     RT_DEVICE(c);
-    RT_HIP(c, hipStreamSynchronize(c->copy_stream));  // no copy of this ctx may still target the block
+    if (c->multi) RT_HIP(c, hipStreamSynchronize(c->parts[0]->stream));
+    else RT_HIP(c, hipStreamSynchronize(c->copy_stream));  // no copy of this ctx may still target the block
     RT_HIP(c, hipHostFree(p));
     return RT_OK;
 }

@@ -260,7 +260,12 @@ public:
     std::vector<uint8_t> last_frame;  // copy of the pixels before clear() (the reference only keeps result.png)
 
     Renderer(Framebuffer frame, std::vector<Element> elements_, std::vector<DynLight> lights_, int32_t device_id = 0)
-        : elements(std::move(elements_)), lights(std::move(lights_)), frame_(std::move(frame)), device_(device_id)
+        : elements(std::move(elements_)), lights(std::move(lights_)), frame_(std::move(frame)), devices_(1, device_id)
+    {
+    }
+    // One row band per entry of `device_ids` (display.rs:90-93's row split across GPUs), gathered to device_ids[0] inside the library.
+    Renderer(Framebuffer frame, std::vector<Element> elements_, std::vector<DynLight> lights_, std::vector<int32_t> device_ids)
+        : elements(std::move(elements_)), lights(std::move(lights_)), frame_(std::move(frame)), devices_(std::move(device_ids))
     {
     }
     ~Renderer() { rt_ctx_destroy(ctx_); }
@@ -274,7 +279,7 @@ public:
     {
         if (depth == 0) throw Error("attempt to subtract with overflow: depth - 1 (renderer.rs:36)");
         if (depth > 0xFFFFFFFFull) throw Error("depth too large");
-        if (!ctx_) check(rt_ctx_create(&ctx_, device_), nullptr);
+        if (!ctx_) check(devices_.size() == 1 ? rt_ctx_create(&ctx_, devices_[0]) : rt_ctx_create_multi(&ctx_, devices_.data(), (int32_t)devices_.size()), nullptr);
         upload();
         float m[16];
         frame_.camera.transform(frame_.aspect_ratio(), m);
@@ -318,7 +323,7 @@ private:
     }
 
     Framebuffer frame_;
-    int32_t device_;
+    std::vector<int32_t> devices_;
     rt_ctx* ctx_ = nullptr;
 };
 

@@ -184,17 +184,19 @@ class Framebuffer:
 class Renderer:
     """renderer.rs:12-82. `render(depth)` runs the pixel loop on the GPU, then display() and clear() like the reference."""
 
-    def __init__(self, frame: Framebuffer, elements: Sequence[Element], lights: Sequence, device_id: int = 0):
+    def __init__(self, frame: Framebuffer, elements: Sequence[Element], lights: Sequence, device_id: int = 0,
+                 device_ids: Optional[Sequence[int]] = None):
         self.frame = frame
         self.elements = list(elements)
         self.lights = list(lights)
         self._ctx: Optional[capi.Context] = None
         self._device_id = device_id
+        self._device_ids = list(device_ids) if device_ids is not None else None  # one row band per entry (rt_ctx_create_multi)
         self.last_frame: Optional[np.ndarray] = None
 
     def _context(self) -> capi.Context:
         if self._ctx is None:
-            self._ctx = capi.Context(self._device_id)
+            self._ctx = capi.Context(self._device_id, device_ids=self._device_ids)
         return self._ctx
 
     def render(self, depth: int, flags: int = 0, display_path: Optional[str] = "result.png"):

@@ -49,6 +49,8 @@ pub struct rt_ctx {
 extern "C" {
     pub fn rt_version() -> *const c_char;
     pub fn rt_ctx_create(out: *mut *mut rt_ctx, device_id: i32) -> i32;
+    /// One context over a device list: every entry renders one row band, gathered to device_ids[0] by RCCL inside the library.
+    pub fn rt_ctx_create_multi(out: *mut *mut rt_ctx, device_ids: *const i32, n_devices: i32) -> i32;
     pub fn rt_ctx_destroy(ctx: *mut rt_ctx) -> i32;
     pub fn rt_last_error(ctx: *const rt_ctx) -> *const c_char;
     pub fn rt_camera_transform(fov: f32, z_near: f32, z_far: f32, aspect_ratio: f32, m: *mut f32) -> i32;

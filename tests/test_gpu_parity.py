@@ -601,3 +601,82 @@ def test_general_launches_on_different_streams_are_ordered(oracle):
         torch.cuda.synchronize()
         for k in range(6):
             _assert_same(outs[k].cpu().numpy(), refs[k % 3], f"general launch {k}")
+
+
+def test_multi_device_context_virtual_bands(oracle):
+    """rt_ctx_create_multi: the band split and the RCCL gather BEHIND the C ABI.  One GPU here, so the device list
+    repeats device 0 ("virtual bands"): bands 1.. are rendered into staging and travel through the library's own RCCL group (a send of
+    the device to itself) into their rows of the frame — every call a real multi-GPU run makes except the link.  Byte-equal to the
+    single launch: C3 at full size with {1, 8} bands through rt_render (host store), hit-index plane, RGB8, odd heights with
+    3 and 5 bands, the general path, the device-resident entry point on a caller stream, and errors."""
+    import torch
+    w, h, objs, lights = scenegen.config("C3")
+    m = _cam(oracle, w, h)
+    with capi.Context(0) as one:
+        one.scene_upload(objs, lights)
+        ref, ref_hit = one.render_rows(m, w, h, 0, h, 1, 0, want_hit_idx=True)
+    oref = oracle.render(objs, lights, m, w, h, row_step=120)
+    _assert_same(ref[::120], oref[::120], "single-launch C3 vs the oracle")
+    for ids in ([0], [0] * 8):
+        with capi.Context(device_ids=ids) as ctx:
+            ctx.scene_upload(objs, lights)
+            got = ctx.render(m, w, h, 1, 0)
+            _assert_same(got, ref, f"C3 through rt_render, device list {ids}")
+            assert ctx.last_kernel_ms() > 0.1
+            if len(ids) > 1:
+                got, hit = ctx.render_rows(m, w, h, 0, h, 1, 0, want_hit_idx=True)
+                _assert_same(got, ref, "C3, 8 bands, with the hit-index plane")
+                assert np.array_equal(hit, ref_hit)
+                rgb = ctx.render(m, w, h, 1, capi.RT_OUT_RGB8)
+                _assert_same(rgb, ref[..., :3], "C3, 8 bands, RGB8")
+                band = ctx.render_rows(m, w, h, 1001, 1100)[0]  # 99 rows over 8 bands: uneven bands
+                _assert_same(band, ref[1001:1100], "a 99-row band over 8 bands")
+                # device-resident entry point on a caller stream, several frames back to back
+                st = torch.cuda.Stream()
+                frames = [torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda") for _ in range(3)]
+                for f in frames:
+                    ctx.render_rows_device(m, w, h, 0, h, 1, 0, f.data_ptr(), 0, st.cuda_stream)
+                st.synchronize()
+                for f in frames:
+                    _assert_same(f.cpu().numpy(), ref, "rt_render_rows_device on a multi-device context")
+                with pytest.raises(capi.RtError) as e:
+                    ctx.render_rows_device_noalloc(m, w, h, 0, h, 1, 0, frames[0].data_ptr(), 0, st.cuda_stream)
+                assert e.value.code == capi.RT_ERR_INVALID
+    # odd sizes, more bands than rows, the general path (every band's kernels use its part's hit records, in stream order)
+    w, h = 333, 77
+    objs, lights = scenegen.generate(w, h, 300, 5, seed=3)
+    m = _cam(oracle, w, h)
+    for n_bands in (3, 5, 64):
+        with capi.Context(device_ids=[0] * n_bands) as ctx:
+            ctx.scene_upload(objs, lights)
+            for depth, flags in ((1, 0), (2, capi.RT_SHADOWS), (1, capi.RT_SHADOWS | capi.RT_OUT_RGB8)):
+                got, hit = ctx.render_rows(m, w, h, 0, h, depth, flags, want_hit_idx=True)
+                oref, ohit = oracle.render(objs, lights, m, w, h, depth=depth, flags=flags & 1, channels=3 if flags & 2 else 4, want_hit_idx=True)
+                _assert_same(got, oref, f"{n_bands} bands, depth {depth}, flags {flags}")
+                assert np.array_equal(hit, ohit)
+            tiny = ctx.render_rows(m, w, h, 10, 12)[0]  # 2 rows over n bands: most bands are empty
+            _assert_same(tiny, oracle.render(objs, lights, m, w, h, y0=10, y1=12), f"2 rows over {n_bands} bands")
+            with pytest.raises(capi.RtError):
+                ctx.render(m, w, h, 0)
+    with pytest.raises(capi.RtError) as e:
+        capi.Context(device_ids=[0, 99])
+    assert e.value.code == capi.RT_ERR_NO_DEVICE
+    with pytest.raises(capi.RtError):
+        capi.Context(device_ids=[])
+
+
+def test_multi_device_through_host_mirrors(tmp_path):
+    """examples/main with RT_DEVICES=0,0,0 (a process without torch: the library loads RCCL itself) and the Python Renderer mirror with
+    a device list both write the reference's result.png."""
+    import subprocess
+    gold = np.load(os.path.join(GOLDEN, "result_100x100.npy"))
+    exe = os.path.abspath(os.path.join(os.path.dirname(GOLDEN), "..", "examples", "main"))
+    env = dict(os.environ, RT_DEVICES="0,0,0")
+    r = subprocess.run([exe], cwd=tmp_path, capture_output=True, text=True, timeout=180, env=env)
+    assert r.returncode == 0, r.stderr
+    from PIL import Image
+    _assert_same(np.array(Image.open(tmp_path / "result.png")), gold, "C++ main, three virtual bands")
+    elements, lights = scene.default_scene()
+    rr = scene.Renderer(scene.Framebuffer(100, 100, scene.Camera()), elements, lights, device_ids=[0, 0, 0, 0, 0])
+    rr.render(1, display_path=None)
+    _assert_same(rr.last_frame, gold, "Python Renderer mirror, five virtual bands")
