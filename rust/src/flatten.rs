@@ -21,31 +21,46 @@ pub struct FlatLight {
     pub intensity: f32,
 }
 
-// --- object/mod.rs: add to `pub trait Object` ---------------------------------------------------------
-//     fn flatten(&self) -> Option<FlatObject> { None }
-// and to each blanket impl (`&T`, `Box<T>`, `Arc<T>`):
-//     #[inline] fn flatten(&self) -> Option<FlatObject> { T::flatten(self) }
+// The trait methods themselves have to live in the trait definitions (a foreign module cannot add a method to `dyn Object`), and
+// `Ambient.color` is private to light/ambient.rs, so these are the lines to paste there:
+//
+//   object/mod.rs, in `pub trait Object`:            fn flatten(&self) -> Option<FlatObject> { None }
+//   object/mod.rs, in each blanket impl (&T, Box<T>, Arc<T>):   #[inline] fn flatten(&self) -> Option<FlatObject> { T::flatten(self) }
+//   object/sphere.rs, in `impl Object for Sphere`:   #[inline] fn flatten(&self) -> Option<FlatObject> { Some(self.flat()) }
+//   light/mod.rs, in `pub trait Light`:              fn flatten(&self) -> Option<FlatLight> { None }
+//   light/mod.rs, in each blanket impl:              #[inline] fn flatten(&self) -> Option<FlatLight> { T::flatten(self) }
+//   light/point.rs, in `impl Light for Point`:       #[inline] fn flatten(&self) -> Option<FlatLight> { Some(self.flat()) }
+//   light/ambient.rs, in `impl Light for Ambient`:   #[inline] fn flatten(&self) -> Option<FlatLight> {
+//                                                        Some(FlatLight { kind: RT_AMBIENT, point: [0.0; 3], color: self.color.to_array(), intensity: 0.0 }) }
+//
+// The flat forms of the types whose fields are public are real items here:
 
-// --- object/sphere.rs: add to `impl Object for Sphere` -------------------------------------------------
-//     #[inline]
-//     fn flatten(&self) -> Option<FlatObject> {
-//         Some(FlatObject { kind: RT_SPHERE, center: self.center.to_array(), radius: self.radius, normal: [0.0; 3] })
-//     }
+impl crate::object::Sphere {
+    /// object/sphere.rs:6-9
+    #[inline]
+    pub fn flat(&self) -> FlatObject {
+        FlatObject { kind: RT_SPHERE, center: self.center.to_array(), radius: self.radius, normal: [0.0; 3] }
+    }
 
-// --- light/mod.rs: add to `pub trait Light` (+ blanket impls) ------------------------------------------
-//     fn flatten(&self) -> Option<FlatLight> { None }
+    /// The sphere after an object `Transform` (math/mod.rs:5-51): centre through `Transform::apply` (math/mod.rs:40-43), radius times
+    /// the scale — defined only for a uniform scale (anything else is an ellipsoid, which `Sphere` cannot express): `None` then.
+    /// Nothing in the reference attaches a Transform to an object; this is the host-side pre-transform of SURVEY 8(f) row 4.
+    pub fn transformed(&self, t: crate::math::Transform) -> Option<Self> {
+        let s = t.scale.to_array();
+        if !(s[0] == s[1] && s[1] == s[2]) {
+            return None;
+        }
+        Some(Self::new(t.apply(self.center), self.radius * s[0].abs()))
+    }
+}
 
-// --- light/point.rs ------------------------------------------------------------------------------------
-//     #[inline]
-//     fn flatten(&self) -> Option<FlatLight> {
-//         Some(FlatLight { kind: RT_POINT, point: self.point.to_array(), color: self.color.to_array(), intensity: self.intensity })
-//     }
-
-// --- light/ambient.rs ----------------------------------------------------------------------------------
-//     #[inline]
-//     fn flatten(&self) -> Option<FlatLight> {
-//         Some(FlatLight { kind: RT_AMBIENT, point: [0.0; 3], color: self.color.to_array(), intensity: 0.0 })
-//     }
+impl crate::light::Point {
+    /// light/point.rs:5-9
+    #[inline]
+    pub fn flat(&self) -> FlatLight {
+        FlatLight { kind: RT_POINT, point: self.point.to_array(), color: self.color.to_array(), intensity: self.intensity }
+    }
+}
 
 /// SoA buffers handed to `rt_scene_upload`; element / light order is preserved (renderer.rs:49-53, :60-64).
 #[derive(Default)]

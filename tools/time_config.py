@@ -11,13 +11,14 @@ ap.add_argument("--shadows", action="store_true")
 ap.add_argument("--depth", type=int, default=1)
 ap.add_argument("--frames", type=int, default=5)
 ap.add_argument("--rows", default=None)
+ap.add_argument("--rgb8", action="store_true", help="RT_OUT_RGB8: 3 B/pixel, the layout of Framebuffer.pixels")
 a = ap.parse_args()
 w, h, objs, lights = scenegen.config(a.config)
 y0, y1 = (0, h) if a.rows is None else map(int, a.rows.split(":"))
 m = capi.camera_transform(*capi.camera_default(), np.float32(w) / np.float32(h))
 import torch
 out = torch.zeros(((y1 - y0), w, 4), dtype=torch.uint8, device="cuda")
-flags = capi.RT_SHADOWS if a.shadows else 0
+flags = (capi.RT_SHADOWS if a.shadows else 0) | (capi.RT_OUT_RGB8 if a.rgb8 else 0)
 with capi.Context(0) as ctx:
     ctx.scene_upload(objs, lights)
     import time
@@ -31,6 +32,6 @@ with capi.Context(0) as ctx:
         ms.append(ctx.last_kernel_ms())
     ms = ms[1:]
     rays = (y1 - y0) * w
-    print("%s rows %d:%d depth=%d shadows=%d: kernel ms min/med = %.3f / %.3f  -> %.3e primary rays/s; lit pixels %.1f%%"
-          % (a.config, y0, y1, a.depth, int(a.shadows), min(ms), sorted(ms)[len(ms) // 2], rays / (sorted(ms)[len(ms) // 2] * 1e-3),
+    print("%s rows %d:%d depth=%d shadows=%d rgb8=%d: kernel ms min/med = %.3f / %.3f  -> %.3e primary rays/s; lit pixels %.1f%%"
+          % (a.config, y0, y1, a.depth, int(a.shadows), int(a.rgb8), min(ms), sorted(ms)[len(ms) // 2], rays / (sorted(ms)[len(ms) // 2] * 1e-3),
              100.0 * float((out[..., :3].sum(dim=-1) > 0).float().mean())))
