@@ -103,6 +103,14 @@ int32_t rt_camera_transform(float fov, float z_near, float z_far, float aspect_r
 int32_t rt_camera_default(float* fov, float* z_near, float* z_far);
 
 /*
+ * Transform::apply (math/mod.rs:40-43): out = position + rotation.apply(v) (x) scale, rotation = a versor (r, i, j, k) applied as
+ * (q * (0, v)) * conj(q) (quat.rs:159-166, quaternion product of quat.rs:201-226, same lane arithmetic).  Host-only helper: the
+ * reference attaches no Transform to any object, so the host mirrors use this to pre-transform a sphere's centre
+ * before flattening (radius x scale, uniform scale only); nothing of it runs on the device.
+ */
+int32_t rt_transform_apply(const float position[3], const float versor[4], const float scale[3], const float v[3], float out[3]);
+
+/*
  * Replaces the borrow of self.elements / self.lights at renderer.rs:37-38: copies the flattened scene to the device and
  * precomputes the per-sphere constants the kernels use.  May be called again to replace the scene.
  */

@@ -68,6 +68,36 @@ void rto_camera_transform(float fov, float z_near, float z_far, float aspect, fl
     m[14] = -1.0f;
 }
 
+/* quat.rs:201-226 — Hamilton product in the reference's lane order: (t0 - t3) + ((t1 + t2) * (-1, 1, 1, 1)), quaternions as (r, i, j, k) */
+static void quat_mul(const float a[4], const float b[4], float out[4])
+{
+    const float t1[4] = {a[1] * b[1], a[1] * b[0], a[2] * b[0], a[3] * b[0]};
+    const float t2[4] = {a[2] * b[2], a[2] * b[3], a[3] * b[1], a[1] * b[2]};
+    const float t3[4] = {a[3] * b[3], a[3] * b[2], a[1] * b[3], a[2] * b[1]};
+    const float sg[4] = {-1.0f, 1.0f, 1.0f, 1.0f};
+    for (int k = 0; k < 4; ++k) {
+        float t12 = t1[k] + t2[k];
+        float t12m = t12 * sg[k];
+        float t0 = a[0] * b[k];
+        float t03 = t0 - t3[k];
+        out[k] = t03 + t12m;
+    }
+}
+
+/* math/mod.rs:40-43 Transform::apply = position + rotation.apply(v).wide_mul(scale); quat.rs:159-166 Versor::apply = (q * (0, v)) * conj(q) */
+void rto_transform_apply(const float position[3], const float versor[4], const float scale[3], const float v[3], float out[3])
+{
+    const float p[4] = {0.0f, v[0], v[1], v[2]};
+    const float inv[4] = {versor[0] * 1.0f, versor[1] * -1.0f, versor[2] * -1.0f, versor[3] * -1.0f}; /* quat.rs:145-147 */
+    float qp[4], res[4];
+    quat_mul(versor, p, qp);
+    quat_mul(qp, inv, res);
+    for (int k = 0; k < 3; ++k) {
+        float scaled = res[k + 1] * scale[k];
+        out[k] = position[k] + scaled;
+    }
+}
+
 /* vec4.rs:119-121 dot ; vec4.rs:84-116 reduce_add = (p0+p1)+(p2+p3) */
 static inline float dot4(const float* r, const float* v)
 {

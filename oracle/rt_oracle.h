@@ -52,6 +52,9 @@ typedef struct {
 float rto_default_fov(void);
 /* display.rs:30-41 — Camera::transform, row-major 4x4 */
 void rto_camera_transform(float fov, float z_near, float z_far, float aspect, float m[16]);
+/* math/mod.rs:40-43 (Transform::apply) over quat.rs:159-166 (Versor::apply) and quat.rs:201-226 (quaternion product); versor = (r, i, j, k).
+ * Nothing in the reference attaches a Transform to an object: host-side pre-transform of sphere centres only. */
+void rto_transform_apply(const float position[3], const float versor[4], const float scale[3], const float v[3], float out[3]);
 /* mat4.rs:180-192 + vec4.rs:84-121 — Mat4 * Vec4 with the SSE reduce order (p0+p1)+(p2+p3) */
 void rto_mat4_mul_vec4(const float m[16], const float v[4], float out[4]);
 /* vec3.rs:118-155 — dot with (xx+yy)+(zz+0) order */

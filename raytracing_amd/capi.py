@@ -31,7 +31,7 @@ LIB_PATH = os.environ.get("RT_MI355X_LIB") or os.path.join(os.path.dirname(os.pa
 EXPORTS = (
     "rt_version", "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_camera_transform", "rt_camera_default",
     "rt_scene_upload", "rt_render", "rt_render_rows", "rt_render_rows_device", "rt_last_kernel_ms",
-    "rt_debug_prepare_spheres", "rt_host_alloc", "rt_host_free", "rt_debug_tile_plan", "rt_render_rows_device_noalloc", "rt_last_phase_ms", "rt_ctx_create_multi",
+    "rt_debug_prepare_spheres", "rt_host_alloc", "rt_host_free", "rt_debug_tile_plan", "rt_render_rows_device_noalloc", "rt_last_phase_ms", "rt_ctx_create_multi", "rt_transform_apply",
 )
 
 _f32p = C.POINTER(C.c_float)
@@ -81,6 +81,7 @@ def load() -> C.CDLL:
     lib.rt_ctx_destroy.argtypes = [vp]
     lib.rt_camera_transform.argtypes = [C.c_float, C.c_float, C.c_float, C.c_float, _f32p]
     lib.rt_camera_default.argtypes = [_f32p, _f32p, _f32p]
+    lib.rt_transform_apply.argtypes = [_f32p, _f32p, _f32p, _f32p, _f32p]
     lib.rt_scene_upload.argtypes = [vp, C.POINTER(RtObjects), C.POINTER(RtLights)]
     lib.rt_debug_tile_plan.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]
     lib.rt_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
@@ -165,6 +166,18 @@ def camera_transform(fov: float, z_near: float, z_far: float, aspect: float) -> 
     if rc != RT_OK:
         raise RtError(rc, "rt_camera_transform")
     return m
+
+
+def transform_apply(position, versor, scale, v) -> np.ndarray:
+    """Transform::apply (math/mod.rs:40-43): position + rotate(versor = (r, i, j, k), v) * scale, in the library's f32 arithmetic."""
+    a = [_f32(x) for x in (position, versor, scale, v)]
+    if [x.size for x in a] != [3, 4, 3, 3]:
+        raise ValueError("position[3], versor[4], scale[3], v[3]")
+    out = np.zeros(3, dtype=np.float32)
+    rc = load().rt_transform_apply(*[x.ctypes.data_as(_f32p) for x in a], out.ctypes.data_as(_f32p))
+    if rc != RT_OK:
+        raise RtError(rc, "rt_transform_apply")
+    return out
 
 
 def camera_default():

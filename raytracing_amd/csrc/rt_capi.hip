@@ -159,6 +159,13 @@ int32_t rt_camera_transform(float fov, float z_near, float z_far, float aspect_r
     return RT_OK;
 }
 
+int32_t rt_transform_apply(const float position[3], const float versor[4], const float scale[3], const float v[3], float out[3])
+{
+    if (!position || !versor || !scale || !v || !out) return RT_ERR_INVALID;
+    transform_apply(position, versor, scale, v, out);
+    return RT_OK;
+}
+
 int32_t rt_camera_default(float* fov, float* z_near, float* z_far)
 {
     if (!fov || !z_near || !z_far) return RT_ERR_INVALID;

@@ -216,4 +216,34 @@ void camera_transform(float fov, float z_near, float z_far, float aspect, float 
     m[14] = -1.0f;
 }
 
+// quat.rs:201-226 with quaternions as (r, i, j, k): per lane (a0 b - t3) + ((t1 + t2) * (-1, 1, 1, 1)), every product and sum rounded
+static void hamilton(const float a[4], const float b[4], float out[4])
+{
+    const float t1[4] = {a[1] * b[1], a[1] * b[0], a[2] * b[0], a[3] * b[0]};
+    const float t2[4] = {a[2] * b[2], a[2] * b[3], a[3] * b[1], a[1] * b[2]};
+    const float t3[4] = {a[3] * b[3], a[3] * b[2], a[1] * b[3], a[2] * b[1]};
+    const float sign[4] = {-1.0f, 1.0f, 1.0f, 1.0f};
+    for (int k = 0; k < 4; ++k) {
+        const float t12 = t1[k] + t2[k];
+        const float t12m = t12 * sign[k];
+        const float t0 = a[0] * b[k];
+        const float t03 = t0 - t3[k];
+        out[k] = t03 + t12m;
+    }
+}
+
+void transform_apply(const float position[3], const float versor[4], const float scale[3], const float v[3], float out[3])
+{
+    // math/mod.rs:40-43: position + rotation.apply(v).wide_mul(scale); quat.rs:159-166: (q * (0, v)) * q.inverse(), inverse = conjugate
+    const float p[4] = {0.0f, v[0], v[1], v[2]};
+    const float inv[4] = {versor[0] * 1.0f, versor[1] * -1.0f, versor[2] * -1.0f, versor[3] * -1.0f};
+    float qp[4], res[4];
+    hamilton(versor, p, qp);
+    hamilton(qp, inv, res);
+    for (int k = 0; k < 3; ++k) {
+        const float scaled = res[k + 1] * scale[k];
+        out[k] = position[k] + scaled;
+    }
+}
+
 }  // namespace rtamd

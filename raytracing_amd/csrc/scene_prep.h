@@ -50,5 +50,7 @@ void prepare_filter(int32_t n, const float* cx, const float* cy, const float* cz
 
 // Camera::transform (display.rs:30-41)
 void camera_transform(float fov, float z_near, float z_far, float aspect, float m[16]);
+// Transform::apply (math/mod.rs:40-43) with Versor::apply (quat.rs:159-166): host-side pre-transform of object centres
+void transform_apply(const float position[3], const float versor[4], const float scale[3], const float v[3], float out[3]);
 
 }  // namespace rtamd

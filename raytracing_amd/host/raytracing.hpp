@@ -42,6 +42,22 @@ struct Vec3 {
 };
 inline Vec3 operator*(float s, Vec3 v) { return Vec3(s * v.x, s * v.y, s * v.z); }  // vec3.rs:467-474
 
+// math/mod.rs:5-51 — Transform: position, rotation (a versor as r, i, j, k; quat.rs), scale.  The reference never attaches one to an
+// object; the mirror applies it on the host before flattening (Sphere::transformed).  The arithmetic is the library's
+// rt_transform_apply (same lane order as quat.rs:201-226).
+struct Transform {
+    Vec3 position;
+    float rotation[4] = {1.0f, 0.0f, 0.0f, 0.0f};
+    Vec3 scale = Vec3(1.0f, 1.0f, 1.0f);
+    Vec3 apply(Vec3 v) const  // math/mod.rs:40-43
+    {
+        const float p[3] = {position.x, position.y, position.z}, s[3] = {scale.x, scale.y, scale.z}, in[3] = {v.x, v.y, v.z};
+        float out[3];
+        rt_transform_apply(p, rotation, s, in, out);
+        return Vec3(out[0], out[1], out[2]);
+    }
+};
+
 // What a scene object / light hands to the FFI (the Rust adapter's `flatten()`)
 struct FlatObject {
     uint8_t kind;
@@ -66,6 +82,12 @@ struct Sphere final : Object {
     float radius = 0.0f;
     Sphere() = default;
     Sphere(Vec3 c, float r) : center(c), radius(r) {}
+    // The sphere after an object Transform: centre through Transform::apply, radius times the (uniform) scale.
+    Sphere transformed(const Transform& t) const
+    {
+        if (!(t.scale.x == t.scale.y && t.scale.y == t.scale.z)) throw std::invalid_argument("a Sphere can only take a uniform scale");
+        return Sphere(t.apply(center), radius * std::fabs(t.scale.x));
+    }
     bool flatten(FlatObject& f) const override
     {
         f = FlatObject{(uint8_t)RT_SPHERE, center.x, center.y, center.z, radius, 0.0f, 0.0f, 0.0f};

@@ -47,6 +47,28 @@ class Sphere:
     def flatten(self):
         return (capi.RT_SPHERE, self.center.x, self.center.y, self.center.z, self.radius)
 
+    def transformed(self, t: "Transform") -> "Sphere":
+        """The sphere after an object Transform (math/mod.rs:5-51): centre through Transform::apply, radius times the scale.
+        Uniform scale only — anything else is an ellipsoid, which Sphere (object/sphere.rs:6-9) cannot express."""
+        s = t.scale
+        if not (s.x == s.y == s.z):
+            raise ValueError("a Sphere can only take a uniform scale")
+        c = capi.transform_apply(t.position.to_array(), t.rotation, t.scale.to_array(), self.center.to_array())
+        return Sphere(Vec3(float(c[0]), float(c[1]), float(c[2])), float(np.float32(self.radius) * np.float32(abs(s.x))))
+
+
+@dataclass(frozen=True)
+class Transform:
+    """math/mod.rs:5-51 — position, rotation (a versor as (r, i, j, k), quat.rs), scale.  The reference never attaches one to an
+    object; the mirrors apply it on the host before flattening (Sphere.transformed)."""
+    position: Vec3 = Vec3(0.0, 0.0, 0.0)
+    rotation: tuple = (1.0, 0.0, 0.0, 0.0)
+    scale: Vec3 = Vec3(1.0, 1.0, 1.0)
+
+    def apply(self, v: Vec3) -> Vec3:
+        o = capi.transform_apply(self.position.to_array(), self.rotation, self.scale.to_array(), v.to_array())
+        return Vec3(float(o[0]), float(o[1]), float(o[2]))
+
 
 @dataclass(frozen=True)
 class Plane:

@@ -55,6 +55,8 @@ extern "C" {
     pub fn rt_last_error(ctx: *const rt_ctx) -> *const c_char;
     pub fn rt_camera_transform(fov: f32, z_near: f32, z_far: f32, aspect_ratio: f32, m: *mut f32) -> i32;
     pub fn rt_camera_default(fov: *mut f32, z_near: *mut f32, z_far: *mut f32) -> i32;
+    /// Transform::apply (math/mod.rs:40-43) in the library's arithmetic; a Rust host calls `Transform::apply` itself instead.
+    pub fn rt_transform_apply(position: *const f32, versor: *const f32, scale: *const f32, v: *const f32, out: *mut f32) -> i32;
     pub fn rt_scene_upload(ctx: *mut rt_ctx, objects: *const rt_objects, lights: *const rt_lights) -> i32;
     pub fn rt_render(ctx: *mut rt_ctx, m: *const f32, w: u32, h: u32, depth: u32, flags: u32, out_host: *mut u8) -> i32;
     pub fn rt_render_rows(ctx: *mut rt_ctx, m: *const f32, w: u32, h: u32, y0: u32, y1: u32, depth: u32, flags: u32,

@@ -52,6 +52,7 @@ class Oracle:
         lib.rto_render.argtypes = [C.POINTER(RtoObjects), C.POINTER(RtoLights), _f32p] + [C.c_uint32] * 8 + [C.c_void_p, C.c_void_p, C.c_int]
         lib.rto_render.restype = C.c_int
         lib.rto_default_threads.restype = C.c_int
+        lib.rto_transform_apply.argtypes = [_f32p] * 5
 
     @staticmethod
     def _v(a):
@@ -119,6 +120,12 @@ class Oracle:
         if rc != 0:
             raise ValueError("rto_render rejected the arguments")
         return (out, hit) if want_hit_idx else out
+
+    def transform_apply(self, position, versor, scale, v):
+        a = [self._v(x) for x in (position, versor, scale, v)]
+        out = np.zeros(3, np.float32)
+        self.lib.rto_transform_apply(*[_p(x, _f32p) for x in a], _p(out, _f32p))
+        return out
 
     def default_threads(self):
         return int(self.lib.rto_default_threads())

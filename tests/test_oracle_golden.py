@@ -170,3 +170,36 @@ def test_plane_extension_known_answers(oracle):
     assert hit2[32, 32] == 1 and hit2[0, 0] == 0
     with pytest.raises(ValueError):
         oracle.render(capi.FlatObjects([0], [0], [-5], [0], [1], [1], [1], kind=np.array([1], np.uint8)), lights, m, 8, 8)  # plane without normals
+
+
+def test_transform_apply_matches_the_reference_formula(oracle):
+    """Transform::apply (math/mod.rs:40-43) = position + Versor::apply(v) (x) scale (quat.rs:159-166, 201-226): the library's
+    host helper is bit-identical to the oracle's restatement; both agree with a float64 rotation to rounding; known rotations.
+    The reference's own math::test (math/mod.rs:53-65) only prints, so there is no reference number to pin: parity unpinned."""
+    from raytracing_amd import capi, scene
+    rng = np.random.default_rng(7)
+    f = np.float32
+    for _ in range(200):
+        q = rng.standard_normal(4)
+        q = (q / np.linalg.norm(q)).astype(f)
+        pos, scl, v = (rng.standard_normal(3) * 5).astype(f), (rng.random(3) * 3 + 0.1).astype(f), (rng.standard_normal(3) * 10).astype(f)
+        got = capi.transform_apply(pos, q, scl, v)
+        ref = oracle.transform_apply(pos, q, scl, v)
+        assert got.tobytes() == ref.tobytes()
+        r, i, j, k = [float(x) for x in q]
+        rot = np.array([[1 - 2 * (j * j + k * k), 2 * (i * j - k * r), 2 * (i * k + j * r)],
+                        [2 * (i * j + k * r), 1 - 2 * (i * i + k * k), 2 * (j * k - i * r)],
+                        [2 * (i * k - j * r), 2 * (j * k + i * r), 1 - 2 * (i * i + j * j)]])
+        want = pos.astype(np.float64) + (rot @ v.astype(np.float64)) * scl.astype(np.float64)
+        assert np.allclose(got, want, rtol=0, atol=2e-5 * (1 + np.abs(want).max()))
+    h = f(np.sqrt(0.5))
+    quarter_z = (h, 0, 0, h)  # 90 degrees about z: x -> y
+    assert np.allclose(capi.transform_apply((0, 0, 0), quarter_z, (1, 1, 1), (1, 0, 0)), (0, 1, 0), atol=1e-6)
+    assert capi.transform_apply((1, 2, 3), (1, 0, 0, 0), (1, 1, 1), (4, 5, 6)).tolist() == [5, 7, 9]  # identity rotation is exact
+    # the mirrors' Sphere.transformed: centre through apply, radius x uniform scale; non-uniform scale is refused
+    t = scene.Transform(scene.Vec3(1.0, 1.0, 0.0), quarter_z, scene.Vec3.splat(0.5))
+    s = scene.Sphere(scene.Vec3(2.0, 0.0, -4.0), 3.0).transformed(t)
+    assert np.allclose((s.center.x, s.center.y, s.center.z), (1.0, 2.0, -2.0), atol=1e-6) and s.radius == 1.5
+    assert t.apply(scene.Vec3(2.0, 0.0, -4.0)) == s.center
+    with pytest.raises(ValueError):
+        scene.Sphere(scene.Vec3(0.0, 0.0, 0.0), 1.0).transformed(scene.Transform(scale=scene.Vec3(1.0, 2.0, 1.0)))
