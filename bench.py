@@ -46,6 +46,9 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    # the pool's host driver supports dmabuf IPC only: RCCL / cross-process device memory needs this before HIP starts (the GPU boxes
+    # export it already; set here so that a hand-started multi-rank run works too)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import numpy as np
     import torch
     import torch.distributed as dist

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "rt_mi355x.h"
 #include "scenegen.hpp"
@@ -40,7 +41,21 @@ int main(int argc, char** argv)
         return 2;
     }
     rt_ctx* ctx = nullptr;
-    if (rt_ctx_create(&ctx, 0) != RT_OK) return fail("rt_ctx_create", nullptr);
+    // RT_DEVICES=0,1,2,3,4,5,6,7 (or 0,0,0,0: virtual bands on one GPU): one context over a device list, the row-band split and the RCCL
+    // gather happen inside rt_render (rt_ctx_create_multi)
+    std::vector<int32_t> devices;
+    if (const char* env = std::getenv("RT_DEVICES"))
+        for (const char* p = env; *p;) {
+            char* end = nullptr;
+            const long d = std::strtol(p, &end, 10);
+            if (end == p) break;
+            devices.push_back((int32_t)d);
+            p = *end == ',' ? end + 1 : end;
+        }
+    if (devices.size() > 1) {
+        if (rt_ctx_create_multi(&ctx, devices.data(), (int32_t)devices.size()) != RT_OK) return fail("rt_ctx_create_multi", nullptr);
+        std::printf("multi-device context: %zu row bands, root device %d\n", devices.size(), devices[0]);
+    } else if (rt_ctx_create(&ctx, devices.empty() ? 0 : devices[0]) != RT_OK) return fail("rt_ctx_create", nullptr);
     const rt_objects o = sc.objects();
     const rt_lights l = sc.lights();
     if (rt_scene_upload(ctx, &o, &l) != RT_OK) return fail("rt_scene_upload", ctx);

@@ -676,6 +676,16 @@ def test_multi_device_through_host_mirrors(tmp_path):
     assert r.returncode == 0, r.stderr
     from PIL import Image
     _assert_same(np.array(Image.open(tmp_path / "result.png")), gold, "C++ main, three virtual bands")
+    # the native harness over four virtual bands renders the bytes of the single-device run
+    bench = os.path.abspath(os.path.join(os.path.dirname(GOLDEN), "..", "examples", "bench_scene"))
+    dumps = []
+    for tag, e in (("one", dict(os.environ)), ("four", dict(os.environ, RT_DEVICES="0,0,0,0"))):
+        dump = tmp_path / f"c3_{tag}.rgba"
+        r = subprocess.run([bench, "C3", "2", "0", "1", str(dump)], capture_output=True, text=True, timeout=300, env=e)
+        assert r.returncode == 0, r.stderr
+        assert ("multi-device context: 4 row bands" in r.stdout) == (tag == "four")
+        dumps.append(np.fromfile(dump, dtype=np.uint8))
+    assert np.array_equal(dumps[0], dumps[1]) and dumps[0].any()
     elements, lights = scene.default_scene()
     rr = scene.Renderer(scene.Framebuffer(100, 100, scene.Camera()), elements, lights, device_ids=[0, 0, 0, 0, 0])
     rr.render(1, display_path=None)
