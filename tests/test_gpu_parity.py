@@ -288,6 +288,9 @@ def test_fuzz_scenes_cameras_modes(gpu_ctx, oracle):
     rng = np.random.default_rng(int(os.environ.get("RT_FUZZ_SEED", "2024")))
     f = np.float32
     npix = nlit = 0
+    bands = int(os.environ.get("RT_FUZZ_BANDS", "0"))  # soak runs: the same cases through a multi-device context with virtual bands
+    if bands > 0:
+        gpu_ctx = capi.Context(device_ids=[0] * bands)
     for case in range(int(os.environ.get("RT_FUZZ_CASES", "60"))):
         w, h = int(rng.integers(1, 140)), int(rng.integers(1, 90))
         n, nl = int(rng.integers(0, 180)), int(rng.integers(0, 6))
