@@ -83,8 +83,8 @@ int32_t rt_ctx_create(rt_ctx** out, int32_t device_id);
  * them all.  Every entry of `device_ids` is one contiguous ROW BAND: entry g of n renders rows [y0 + rows*g/n, y0 + rows*(g+1)/n) of
  * each rt_render* call with global row indices (display.rs:99) on device device_ids[g]; the scene is replicated by rt_scene_upload;
  * band 0 is rendered in place in the frame on the ROOT device device_ids[0], the other bands into staging on their devices and
- * gathered into their rows of the frame by one group of ncclSend/ncclRecv per call (RCCL over xGMI, loaded at run time: an RCCL
- * already in the process, else $RT_RCCL_LIB, else librccl.so.1).  A device may appear more than once ("virtual bands": such a band
+ * gathered into their rows of the frame by one group of ncclSend/ncclRecv per call (RCCL over xGMI, loaded at run time: $RT_RCCL_LIB if
+ * set, else an RCCL already in the process, else librccl.so.1).  A device may appear more than once ("virtual bands": such a band
  * travels through RCCL too, as a send of the device to itself — how the exchange is exercised on a one-GPU machine).
  * The context works with every rt_* call except rt_render_rows_device_noalloc and rt_last_phase_ms; device pointers and streams
  * passed to rt_render_rows_device belong to the root device.  One host thread issues all launches: at 8 devices a C3-sized frame is

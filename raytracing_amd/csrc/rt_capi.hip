@@ -3,6 +3,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -254,9 +255,14 @@ int32_t rt_ctx_create_multi(rt_ctx** out, const int32_t* device_ids, int32_t n_d
     c->multi = true;
     c->device = device_ids[0];
     std::vector<int> devices;  // distinct, in order of first appearance: devices[0] is the root
+    // TEST HOOK: RT_MULTI_SPLIT_PARTS=1 gives every list entry a part of its own even when devices repeat, so that the per-part logic
+    // (own stream, staging, communicator rank) runs on a one-GPU machine.  Real RCCL refuses two ranks on one device: only usable with
+    // the fake RCCL of tests/fake_rccl (RT_RCCL_LIB).
+    const char* split_env = std::getenv("RT_MULTI_SPLIT_PARTS");
+    const bool split_parts = split_env && split_env[0] == '1';
     for (int32_t g = 0; g < n_devices; ++g) {
         size_t p = 0;
-        while (p < devices.size() && devices[p] != device_ids[g]) ++p;
+        while (p < devices.size() && (split_parts || devices[p] != device_ids[g])) ++p;
         if (p == devices.size()) {
             rt_ctx* part = nullptr;
             const int32_t rc = rt_ctx_create(&part, device_ids[g]);  // error text is already in g_create_err

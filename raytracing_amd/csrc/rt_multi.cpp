@@ -27,15 +27,21 @@ RcclApi g_api;  // loaded once per process (first multi-band context); creation 
 std::string load_api()
 {
     if (g_api.handle) return "";
-    // An RCCL that is already mapped wins (a host that also uses torch.distributed must end up with ONE RCCL in the process); then
-    // RT_RCCL_LIB; then the loader's search path and the ROCm default location.
+    // $RT_RCCL_LIB (an explicit choice) first; else an RCCL that is already mapped (a host that also uses torch.distributed must end up
+    // with ONE RCCL in the process); else the loader's search path and the ROCm default location.
     const char* env = std::getenv("RT_RCCL_LIB");
-    const char* names[] = {"librccl.so", "librccl.so.1"};
     void* h = nullptr;
     std::string where;
+    if (env && *env) {
+        if (!(h = dlopen(env, RTLD_NOW | RTLD_GLOBAL))) {
+            const char* e = dlerror();
+            return std::string("RT_RCCL_LIB=") + env + " could not be loaded: " + (e ? e : "");
+        }
+        where = env;
+    }
+    const char* names[] = {"librccl.so", "librccl.so.1"};
     for (const char* n : names)
         if (!h && (h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) where = std::string(n) + " (already loaded)";
-    if (!h && env && *env && (h = dlopen(env, RTLD_NOW | RTLD_GLOBAL))) where = env;
     const char* paths[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
     for (const char* n : paths)
         if (!h && (h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) where = n;

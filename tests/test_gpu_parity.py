@@ -693,3 +693,18 @@ def test_multi_device_through_host_mirrors(tmp_path):
     rr = scene.Renderer(scene.Framebuffer(100, 100, scene.Camera()), elements, lights, device_ids=[0, 0, 0, 0, 0])
     rr.render(1, display_path=None)
     _assert_same(rr.last_frame, gold, "Python Renderer mirror, five virtual bands")
+
+
+def test_multi_device_parts_with_fake_rccl():
+    """The per-PART logic of a multi-device context (what runs for every device other than the root: own context, stream, staging,
+    communicator rank, peer indices of the sends and receives) on the one-GPU box: tests/fake_rccl stands in for librccl (HIP copies
+    with RCCL's matching and ordering rules; real RCCL refuses two ranks on one device) and RT_MULTI_SPLIT_PARTS=1 gives every list
+    entry its own part.  Own process: a process loads one RCCL.  See tests/multi_parts_worker.py for what is asserted."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    fake = os.path.join(here, "fake_rccl", "libfake_rccl.so")
+    assert os.path.exists(fake), "build it first: make -C tests/fake_rccl (done by __graft_entry__.build())"
+    env = dict(os.environ, RT_RCCL_LIB=fake, RT_MULTI_SPLIT_PARTS="1")
+    r = subprocess.run([sys.executable, os.path.join(here, "multi_parts_worker.py")], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-4000:]
