@@ -161,7 +161,10 @@ __device__ __forceinline__ void shade(const RenderArgs& A, bool active, int k, f
 // A reference hit needs delta = fl(alpha^2) - fl(|q|^2 - r^2) >= 0; fused and unfused evaluation of that expression differ by
 // < 48 u (|q|^2 + r^2) (u = 2^-24), so g >= 0 whenever the reference's delta >= 0.  10 FMA-class ops per (ray, sphere).
 constexpr float kGenDirScale = 1.0f + 1.52587890625e-05f;  // 1 + 2^-16
-constexpr int kGenBlock = 4;                               // spheres per wave vote in the general loops
+#ifndef RT_GEN_BLOCK
+#define RT_GEN_BLOCK 4
+#endif
+constexpr int kGenBlock = RT_GEN_BLOCK;                    // spheres per wave vote in the general loops
 
 template <int P>
 __device__ __forceinline__ float general_filter(int p, const float (&ox)[P], const float (&oy)[P], const float (&oz)[P], const float (&fx)[P],
@@ -217,12 +220,18 @@ __device__ __forceinline__ void trace_general(const RenderArgs& A, float* s_gen,
         __syncthreads();
         if (__builtin_amdgcn_ballot_w64(need != 0u) == 0ull) continue;  // no live ray in this wave (barriers above still run)
         for (int s0 = 0; s0 < cn; s0 += kGenBlock) {
-            const float4 vx = *reinterpret_cast<const float4*>(&s_gen[s0]);
-            const float4 vy = *reinterpret_cast<const float4*>(&s_gen[kChunk + s0]);
-            const float4 vz = *reinterpret_cast<const float4*>(&s_gen[2 * kChunk + s0]);
-            const float4 vw = *reinterpret_cast<const float4*>(&s_gen[3 * kChunk + s0]);
-            const float bx[4] = {vx.x, vx.y, vx.z, vx.w}, by[4] = {vy.x, vy.y, vy.z, vy.w}, bz[4] = {vz.x, vz.y, vz.z, vz.w},
-                        bw[4] = {vw.x, vw.y, vw.z, vw.w};
+            float bx[kGenBlock], by[kGenBlock], bz[kGenBlock], bw[kGenBlock];
+#pragma unroll
+            for (int g = 0; g < kGenBlock; g += 4) {  // wave-uniform addresses: broadcast ds_read_b128, four spheres per read
+                const float4 vx = *reinterpret_cast<const float4*>(&s_gen[s0 + g]);
+                const float4 vy = *reinterpret_cast<const float4*>(&s_gen[kChunk + s0 + g]);
+                const float4 vz = *reinterpret_cast<const float4*>(&s_gen[2 * kChunk + s0 + g]);
+                const float4 vw = *reinterpret_cast<const float4*>(&s_gen[3 * kChunk + s0 + g]);
+                bx[g] = vx.x; bx[g + 1] = vx.y; bx[g + 2] = vx.z; bx[g + 3] = vx.w;
+                by[g] = vy.x; by[g + 1] = vy.y; by[g + 2] = vy.z; by[g + 3] = vy.w;
+                bz[g] = vz.x; bz[g + 1] = vz.y; bz[g + 2] = vz.z; bz[g + 3] = vz.w;
+                bw[g] = vw.x; bw[g + 1] = vw.y; bw[g + 2] = vw.z; bw[g + 3] = vw.w;
+            }
             float m = -1.0f;
 #pragma unroll
             for (int b = 0; b < kGenBlock; ++b)
@@ -807,7 +816,10 @@ inline bool is_general(const RenderArgs& a) { return a.depth > 1u || (a.flags & 
 #define RT_B 16
 #endif
 constexpr int kB = RT_B;       // spheres per wave vote in the primary loop (sweep in profiles/r01_tuning.md)
-constexpr int kShadeP = 2;  // records per lane in shade_iter_kernel
+#ifndef RT_SHADE_P
+#define RT_SHADE_P 2
+#endif
+constexpr int kShadeP = RT_SHADE_P;  // records per lane in shade_iter_kernel
 #ifndef RT_MASK_P
 #define RT_MASK_P 4
 #endif
