@@ -153,7 +153,8 @@ int32_t rt_render_rows_device(rt_ctx* ctx, const float m[16], uint32_t w, uint32
  * 272 + 4 * P * (y1 - y0) * w bytes, P = 3 + (depth > 1 ? 9 : 0) + (RT_SHADOWS ? ceil(n_lights / 32) : 0), and is refused with
  * RT_ERR_TOO_LARGE beyond (e.g. shadows with <= 32 lights: 2.09 Mpixel per call; depth 2: 699 kpixel; cut larger frames into row bands).
  * All calls on one GPU — of any context, of any thread — share that GPU's array: calls that overlap in time on one GPU race; order
- * them (one stream, or events).  Does not update rt_last_kernel_ms.
+ * them (one stream, or events).  Does not update rt_last_kernel_ms.  Capturable: everything the call enqueues is a kernel launch (the
+ * scratch is cleared by a kernel too), so a HIP graph captured around it replays to the same bytes (tests/test_zz_no_alloc.py).
  */
 #define RT_NOALLOC_SCRATCH_BYTES (32u << 20)
 int32_t rt_render_rows_device_noalloc(rt_ctx* ctx, const float m[16], uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t depth,

@@ -810,6 +810,26 @@ __global__ __launch_bounds__(kWaves * 64) void shade_iter_kernel(const RenderArg
     }
 }
 
+// Zeroes scratch words with a KERNEL, not hipMemsetAsync: `planes` planes of `n` words, `stride` words apart, starting at p; plus up to
+// 16 words at q (the tile-queue counters / the record count).  Kernel launches are captured and replayed faithfully by HIP graphs;
+// memset nodes on this scratch were not (replays of a captured RT_SHADOWS launch kept stale occlusion bits), and callers under graph
+// capture are what rt_render_rows_device_noalloc is for.
+__global__ __launch_bounds__(256) void clear_words_kernel(uint32_t* p, size_t n, size_t stride, uint32_t planes, uint32_t* q, uint32_t nq)
+{
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, step = (size_t)gridDim.x * blockDim.x;
+    for (uint32_t pl = 0; pl < planes; ++pl)
+        for (size_t i = i0; i < n; i += step) p[(size_t)pl * stride + i] = 0u;
+    if (i0 < nq) q[i0] = 0u;
+}
+
+inline hipError_t clear_words(uint32_t* p, size_t n, size_t stride, uint32_t planes, uint32_t* q, uint32_t nq, hipStream_t stream)
+{
+    const size_t want = (n + 255) / 256;
+    const uint32_t grid = (uint32_t)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+    hipLaunchKernelGGL(clear_words_kernel, dim3(grid), dim3(256), 0, stream, p, n, stride, planes, q, nq);
+    return hipGetLastError();
+}
+
 inline bool is_general(const RenderArgs& a) { return a.depth > 1u || (a.flags & RT_SHADOWS) != 0u; }
 
 #ifndef RT_B
@@ -922,6 +942,8 @@ hipError_t launch_primary(RenderArgs a, hipStream_t stream)
 }
 }  // namespace
 
+hipError_t clear_scratch_words(uint32_t* q, uint32_t nq, hipStream_t stream) { return clear_words(nullptr, 0, 0, 0, q, nq, stream); }
+
 // The resident-slot caches of the three persistent kernels for the current device (launch_primary / launch_render fill them on first
 // use otherwise): called at context creation so that no render call does set-up work.
 hipError_t prime_launch_caches()
@@ -943,7 +965,7 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream, PhaseEvents
     const uint64_t npix = (uint64_t)(args.y1 - args.y0) * args.w;
     if (!args.rec_count || !args.rec_pix || !args.rec_idx || !args.rec_t || args.rec_cap < npix) return hipErrorInvalidValue;
     if ((args.depth > 1u && !args.rec_state) || (shadows && !args.rec_occ)) return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(args.rec_count, 0, sizeof(uint32_t), stream);
+    hipError_t e = clear_words(nullptr, 0, 0, 0, args.rec_count, 1, stream);
     if (e != hipSuccess) return e;
     if (phases && (e = hipEventRecord(phases->ev[0], stream)) != hipSuccess) return e;
     if ((e = launch_primary<true>(args, stream)) != hipSuccess) return e;
@@ -960,8 +982,7 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream, PhaseEvents
         a.iter = it;
         if (shadows) {
             // only the words of this band's records (at most npix per plane), not the whole capacity of the scratch
-            for (uint32_t wd = 0; wd < occ_words; ++wd)
-                if ((e = hipMemsetAsync(a.rec_occ + (size_t)wd * a.rec_cap, 0, (size_t)npix * sizeof(uint32_t), stream)) != hipSuccess) return e;
+            if ((e = clear_words(a.rec_occ, (size_t)npix, a.rec_cap, occ_words, nullptr, 0, stream)) != hipSuccess) return e;
             const uint64_t worst_tiles = (npix + kWaves * 64 * kMaskP - 1) / (kWaves * 64 * kMaskP) * (uint64_t)args.n_lights;
             if (worst_tiles >= (1ull << 32)) return hipErrorInvalidValue;  // the tile queue counts in 32 bits
             const uint32_t grid = worst_tiles < mask_slots ? (uint32_t)worst_tiles : mask_slots;

@@ -495,7 +495,7 @@ static int32_t enqueue_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h
             return fail(c, RT_ERR_TOO_LARGE, "rt_render_rows_device_noalloc: this band needs " + std::to_string(kNoAllocRecOffset + 16 + npix * planes * 4) +
                                                  " bytes of hit-record scratch, the fixed array holds " + std::to_string((size_t)RT_NOALLOC_SCRATCH_BYTES));
         a.tile_ctr = reinterpret_cast<uint32_t*>(c->noalloc_scratch);
-        RT_HIP(c, hipMemsetAsync(a.tile_ctr, 0, 64, st));
+        RT_HIP(c, clear_scratch_words(a.tile_ctr, 16, st));
         rec_base = reinterpret_cast<char*>(c->noalloc_scratch) + kNoAllocRecOffset;
         rec_cap = npix;
     } else {

@@ -84,3 +84,33 @@ def test_noalloc_limits_and_whole_4k_primary(oracle):
         ctx.render_rows_device_noalloc(m, w, h, 945, 1215, 1, 0, band.data_ptr(), 0, st.cuda_stream)
         st.synchronize()
         assert torch.equal(band, full[945:1215])
+
+
+def test_noalloc_under_hip_graph_capture(oracle):
+    """The callers the entry point is for: captured into a HIP graph (torch.cuda.CUDAGraph) and replayed.  Every replay re-runs the
+    scratch clears (they are kernels: hipMemsetAsync nodes on this scratch did not replay faithfully — stale occlusion bits from the
+    second replay on), so each replay into a cleared buffer gives the bytes of the allocating entry point."""
+    import torch
+    w, h = 1280, 720
+    objs, lights = scenegen.generate(w, h, 400, 4, seed=3)
+    m = oracle.default_camera(w, h)
+    st = torch.cuda.Stream()
+    with capi.Context(0) as ctx:
+        ctx.scene_upload(objs, lights)
+        for depth, flags, rows in ((1, 0, h), (1, capi.RT_SHADOWS, 300), (2, 0, 300), (2, capi.RT_SHADOWS, 300), (1, 0, 64)):
+            want = torch.zeros((rows, w, 4), dtype=torch.uint8, device="cuda")
+            ctx.render_rows_device(m, w, h, 0, rows, depth, flags, want.data_ptr(), 0, st.cuda_stream)
+            st.synchronize()
+            out = torch.zeros((rows, w, 4), dtype=torch.uint8, device="cuda")
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                ctx.render_rows_device_noalloc(m, w, h, 0, rows, depth, flags, out.data_ptr(), 0, st.cuda_stream)
+            for rep in range(3):
+                out.zero_()
+                torch.cuda.synchronize()
+                g.replay()
+                torch.cuda.synchronize()
+                assert torch.equal(out, want), f"depth {depth} flags {flags} rows {rows}: replay {rep} differs"
+            if (depth, flags) == (2, capi.RT_SHADOWS):  # and once against the oracle
+                assert np.array_equal(out.cpu().numpy(), oracle.render(objs, lights, m, w, h, y0=0, y1=rows, depth=2, flags=1))
+            del g
