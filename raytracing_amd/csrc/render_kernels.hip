@@ -835,6 +835,7 @@ inline bool is_general(const RenderArgs& a) { return a.depth > 1u || (a.flags & 
 #ifndef RT_B
 #define RT_B 16
 #endif
+
 constexpr int kB = RT_B;       // spheres per wave vote in the primary loop (sweep in profiles/r01_tuning.md)
 #ifndef RT_SHADE_P
 #define RT_SHADE_P 2
