@@ -37,6 +37,28 @@ def test_no_device_fails_loudly():
     assert e.value.code == capi.RT_ERR_NO_DEVICE
 
 
+def test_multi_device_context_argument_errors_without_a_gpu():
+    """rt_ctx_create_multi: an empty or over-long device list is RT_ERR_INVALID before any device is touched; with no device the
+    first part fails like rt_ctx_create (no fallback).  Nothing of tests/fake_rccl may be referenced by the product either."""
+    import torch
+    with pytest.raises(capi.RtError) as e:
+        capi.Context(device_ids=[])
+    assert e.value.code == capi.RT_ERR_INVALID
+    with pytest.raises(capi.RtError) as e:
+        capi.Context(device_ids=[0] * 65)
+    assert e.value.code == capi.RT_ERR_INVALID
+    if not torch.cuda.is_available():
+        with pytest.raises(capi.RtError) as e:
+            capi.Context(device_ids=[0, 0])
+        assert e.value.code == capi.RT_ERR_NO_DEVICE
+    out = np.zeros(3, np.float32)
+    assert capi.load().rt_transform_apply(None, None, None, None, out.ctypes.data_as(capi._f32p)) == capi.RT_ERR_INVALID
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "raytracing_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp", "Makefile")):
+                assert "fake_rccl" not in open(os.path.join(dirpath, f), errors="ignore").read().replace("tests/fake_rccl", ""), f
+
+
 def test_product_never_imports_the_oracle():
     """The oracle is test infrastructure: nothing under raytracing_amd/ or include/ may reference it."""
     for base in ("raytracing_amd", "include"):
