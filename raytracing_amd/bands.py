@@ -21,6 +21,61 @@ def max_band_rows(h: int, world: int) -> int:
     return max(band_rows(h, world, r)[1] - band_rows(h, world, r)[0] for r in range(world))
 
 
+# ---- cost-balanced cuts: measured by tools/band_balance.py, NOT used by bench.py (profiles/r02_tuning.md: 0-2 % at best, and worse where a
+# band crosses a tile-round boundary of the primary kernel) ----
+
+def equal_cuts(h: int, world: int):
+    """Cut rows of the equal split: cuts[r] .. cuts[r + 1] is band r (the same rows as band_rows)."""
+    return [(r * h) // world for r in range(world)] + [h]
+
+
+def cut_band(cuts, rank: int) -> Tuple[int, int]:
+    return int(cuts[rank]), int(cuts[rank + 1])
+
+
+def fit_cost_model(cuts, times, row_cover):
+    """Least-squares fit of  time(band) = a * rows + b * (hit pixels per row, summed over the band's rows)  to measured per-band
+    times: the filter loop costs the same for every pixel, the exact tail and the shading only where rays hit, so a dense band of
+    equal height takes longer (C3 at 8 bands: 79 against 71 us).  Returns the relative extra cost of a fully covered row,
+    kappa = b / a >= 0 (0 when the fit is degenerate)."""
+    import numpy as np
+    cover = np.asarray(row_cover, dtype=np.float64)
+    rows = np.array([cuts[r + 1] - cuts[r] for r in range(len(cuts) - 1)], dtype=np.float64)
+    hits = np.array([cover[cuts[r]:cuts[r + 1]].sum() for r in range(len(cuts) - 1)], dtype=np.float64)
+    t = np.asarray(times, dtype=np.float64)
+    ok = (rows > 0) & np.isfinite(t) & (t > 0)
+    if ok.sum() < 2:
+        return 0.0
+    A = np.stack([rows[ok], hits[ok]], axis=1)
+    if np.linalg.matrix_rank(A) < 2:
+        return 0.0
+    (a, b), *_ = np.linalg.lstsq(A, t[ok], rcond=None)
+    if not (a > 0) or not np.isfinite(b):
+        return 0.0
+    return float(min(max(b / a, 0.0), 4.0))
+
+
+def balanced_cuts(row_cost, world: int, align: int = 16):
+    """Cut rows of contiguous bands with (nearly) equal summed cost: cuts[0] = 0 < ... <= cuts[world] = h, interior cuts rounded to
+    multiples of `align` rows (16 = the efficient tile height of the primary kernel).  Deterministic: every rank computes the same
+    cuts from the same costs.  A rank may end up with an empty band only if there are fewer aligned rows than ranks."""
+    import numpy as np
+    cost = np.asarray(row_cost, dtype=np.float64)
+    h = int(cost.size)
+    if world < 1 or h < 1 or not np.isfinite(cost).all() or (cost < 0).any() or cost.sum() <= 0:
+        raise ValueError("need a non-negative finite cost per row with a positive sum")
+    cum = np.concatenate([[0.0], np.cumsum(cost)])
+    cuts = [0]
+    for r in range(1, world):
+        y = int(np.searchsorted(cum, cum[-1] * r / world, side="left"))
+        if y > 0 and abs(cum[y - 1] - cum[-1] * r / world) < abs(cum[min(y, h)] - cum[-1] * r / world):
+            y -= 1
+        y = int(round(y / align)) * align
+        cuts.append(min(max(y, cuts[-1]), h))
+    cuts.append(h)
+    return cuts
+
+
 def agree_slots(wanted: int, found: int, world: int, group=None, device=None, floor: int = 2) -> int:
     """Number of frames every rank keeps in flight.  All ranks must rotate over the SAME number of slots (the slot of a frame picks
     its stream, its buffers and its communicator), but each rank may have found a different number of mutually concurrent streams:

@@ -28,6 +28,28 @@ def test_band_rows_partition():
         bands.band_rows(10, 2, 2)
 
 
+def test_cost_balanced_cuts():
+    """bands.balanced_cuts / fit_cost_model (used by tools/band_balance.py): contiguous, aligned, complete, and they equalise the cost."""
+    h = 2160
+    cover = np.zeros(h)
+    cover[700:1500] = 0.5
+    for world in (1, 2, 4, 8):
+        assert bands.equal_cuts(h, world) == [bands.band_rows(h, world, r)[0] for r in range(world)] + [h]
+        cuts = bands.balanced_cuts(1.0 + 0.5 * cover, world)
+        assert cuts[0] == 0 and cuts[-1] == h and len(cuts) == world + 1
+        assert all(a <= b for a, b in zip(cuts[:-1], cuts[1:])) and all(c % 16 == 0 for c in cuts[1:-1])
+        cost = [float((1.0 + 0.5 * cover[a:b]).sum()) for a, b in zip(cuts[:-1], cuts[1:])]
+        assert max(cost) / (sum(cost) / world) < 1.03
+        assert bands.cut_band(cuts, world - 1)[1] == h
+    # the fit recovers kappa from exact band times of the equal split
+    cuts = bands.equal_cuts(h, 8)
+    times = [3.0 * ((b - a) + 0.2 * cover[a:b].sum()) for a, b in zip(cuts[:-1], cuts[1:])]
+    assert abs(bands.fit_cost_model(cuts, times, cover) - 0.2) < 1e-9
+    assert bands.fit_cost_model(cuts, [1.0] * 8, np.zeros(h)) == 0.0  # degenerate: no coverage anywhere
+    with pytest.raises(ValueError):
+        bands.balanced_cuts(np.zeros(10), 2)
+
+
 def test_frame_gather_list_views():
     frame = torch.zeros((8, 3, 4), dtype=torch.uint8)
     views = bands.frame_gather_list(frame, 8, 4)
