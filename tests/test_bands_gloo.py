@@ -39,7 +39,7 @@ def test_cost_balanced_cuts():
         assert cuts[0] == 0 and cuts[-1] == h and len(cuts) == world + 1
         assert all(a <= b for a, b in zip(cuts[:-1], cuts[1:])) and all(c % 16 == 0 for c in cuts[1:-1])
         cost = [float((1.0 + 0.5 * cover[a:b]).sum()) for a, b in zip(cuts[:-1], cuts[1:])]
-        assert max(cost) / (sum(cost) / world) < 1.03
+        assert max(cost) / (sum(cost) / world) < 1.06  # 16-row alignment: +-8 rows of ~270
         assert bands.cut_band(cuts, world - 1)[1] == h
     # the fit recovers kappa from exact band times of the equal split
     cuts = bands.equal_cuts(h, 8)
