@@ -645,6 +645,19 @@ def test_multi_device_context_virtual_bands(oracle):
                 with pytest.raises(capi.RtError) as e:
                     ctx.render_rows_device_noalloc(m, w, h, 0, h, 1, 0, frames[0].data_ptr(), 0, st.cuda_stream)
                 assert e.value.code == capi.RT_ERR_INVALID
+    # BASELINE configs 4 and 5 are the multi-GPU ones: C4 (8K, 8192 spheres) over 2 / 4 / 8 bands and C5 with the shadow extension over
+    # 8 bands, at full size, byte-equal to the single launch (itself checked against the oracle in test_c4_c5_full_size_sampled_rows)
+    for name, flags, splits in (("C4", 0, (2, 4, 8)), ("C5", capi.RT_SHADOWS, (8,))):
+        w, h, objs, lights = scenegen.config(name)
+        m = _cam(oracle, w, h)
+        with capi.Context(0) as one:
+            one.scene_upload(objs, lights)
+            ref = one.render(m, w, h, 1, flags)
+        for n_bands in splits:
+            with capi.Context(device_ids=[0] * n_bands) as ctx:
+                ctx.scene_upload(objs, lights)
+                _assert_same(ctx.render(m, w, h, 1, flags), ref, f"{name} full size over {n_bands} bands")
+        del ref
     # odd sizes, more bands than rows, the general path (every band's kernels use its part's hit records, in stream order)
     w, h = 333, 77
     objs, lights = scenegen.generate(w, h, 300, 5, seed=3)
