@@ -19,8 +19,10 @@ using namespace rtamd;
 struct rt_ctx {
     int device = -1;
     hipStream_t stream = nullptr, copy_stream = nullptr;
+    hipStream_t stream2 = nullptr;  // second render stream of the chunked host-output path (chunks alternate, so one chunk's drain overlaps the next one's ramp)
     hipEvent_t ev0 = nullptr;  // start of the most recent launch (its end: ev_end)
-    hipEvent_t ev_chunk[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_chunk[16] = {};
+    hipEvent_t ev_host_end = nullptr;  // end of the kernels of the most recent host-output call (both render streams)
     bool timed = false;
     std::string err;
     // device copies of the prepared scene
@@ -72,6 +74,7 @@ struct rt_ctx {
     hipEvent_t ev_multi_end = nullptr;
 };
 
+static constexpr uint32_t kHostChunks = 4;   // row chunks of a large frame in the host-output entry points (render / copy pipeline; 6 / 8 / 12 / 16 measured no better, profiles/r02_tuning.md)
 static constexpr uint32_t kTileSlots = 16;  // launches of one context that can be in flight on different streams without waiting for each other
 
 static thread_local std::string g_create_err;
@@ -214,14 +217,19 @@ int32_t rt_ctx_create(rt_ctx** out, int32_t device_id)
     if ((e = guard.status) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreateWithFlags(&c->ev_general, hipEventDisableTiming)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&c->ev_chunk[0], hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&c->ev_chunk[1], hipEventDisableTiming)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&c->ev_chunk[2], hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&c->ev_chunk[3], hipEventDisableTiming)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess || (e = hipEventCreate(&c->ev_host_end)) != hipSuccess ||
         (e = hipMalloc(reinterpret_cast<void**>(&c->d_tile_ctr), kTileSlots * 64)) != hipSuccess ||
         (e = hipMemset(c->d_tile_ctr, 0, kTileSlots * 64)) != hipSuccess) {
         int32_t rc = fail_hip(nullptr, e, "context setup");
         rt_ctx_destroy(c);
         return rc;
     }
+    for (hipEvent_t& ce : c->ev_chunk)
+        if ((e = hipEventCreateWithFlags(&ce, hipEventDisableTiming)) != hipSuccess) {
+            int32_t rc = fail_hip(nullptr, e, "context setup (chunk events)");
+            rt_ctx_destroy(c);
+            return rc;
+        }
     for (hipEvent_t& pe : c->phases.ev)
         if ((e = hipEventCreate(&pe)) != hipSuccess) {
             int32_t rc = fail_hip(nullptr, e, "context setup (phase events)");
@@ -329,7 +337,9 @@ int32_t rt_ctx_destroy(rt_ctx* c)
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_chunk)
         if (e) (void)hipEventDestroy(e);
+    if (c->ev_host_end) (void)hipEventDestroy(c->ev_host_end);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return RT_OK;
@@ -702,31 +712,57 @@ int32_t rt_render_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h, uin
         RT_HIP(c, hipMalloc(&c->d_hit, npix * 4));
         c->d_hit_bytes = npix * 4;
     }
-    // A large band goes out in row chunks: the copy of chunk k to the host (copy stream) overlaps the render of chunk k+1
-    // (ctx stream).  Chunks are row bands, so the image is the single-launch image byte for byte.
+    // A large band goes out in row chunks: the copy of chunk k to the host (copy stream) overlaps the render of the chunks after it.
+    // The chunks are rendered on two alternating streams, so the drain of one launch overlaps the ramp of the next (a chunk alone on
+    // a stream pays ~34 us of launch ramp and drain, profiles/r02_tuning.md).  Chunks are row bands: the image is the single-launch
+    // image byte for byte.  General-path chunks are ordered by the library anyway (shared hit records).
     const size_t bpp = (flags & RT_OUT_RGB8) ? 3 : 4;
     const uint32_t rows = y1 - y0;
-    const uint32_t n_chunks = npix >= (2u << 20) ? 4u : 1u;
+    const uint32_t n_chunks = npix >= (2u << 20) ? kHostChunks : 1u;
+    // two render streams only pay when the copies are asynchronous, i.e. into page-locked memory (rt_host_alloc or the caller's own
+    // hipHostMalloc / hipHostRegister); a pageable destination makes every copy block in the driver and measured 7 % slower with two
+    bool two_streams = false;
+    if (n_chunks > 1) {
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, out_host) == hipSuccess) two_streams = attr.type == hipMemoryTypeHost;
+        else (void)hipGetLastError();  // ordinary memory is "invalid value" to the runtime: not an error of this call
+    }
+    hipStream_t rs[2] = {c->stream, two_streams ? c->stream2 : c->stream};
     RT_HIP(c, hipEventRecord(c->ev0, c->stream));
+    if (two_streams) RT_HIP(c, hipStreamWaitEvent(c->stream2, c->ev0, 0));
+    auto drain = [&]() {
+        (void)hipStreamSynchronize(c->copy_stream);
+        (void)hipStreamSynchronize(c->stream2);
+        (void)hipStreamSynchronize(c->stream);
+    };
+    uint32_t last_of[2] = {n_chunks, n_chunks};
     for (uint32_t k = 0; k < n_chunks; ++k) {
         const uint32_t r0 = (uint32_t)((uint64_t)rows * k / n_chunks), r1 = (uint32_t)((uint64_t)rows * (k + 1) / n_chunks);
         if (r1 == r0) continue;
         const size_t off = (size_t)r0 * w;
+        hipStream_t st = rs[k & 1u];
         rc = enqueue_rows(c, m, w, h, y0 + r0, y0 + r1, depth, flags, static_cast<char*>(c->d_out) + off * bpp,
-                          hit_idx_host ? static_cast<char*>(c->d_hit) + off * 4 : nullptr, c->stream);
+                          hit_idx_host ? static_cast<char*>(c->d_hit) + off * 4 : nullptr, st);
         if (rc != RT_OK) {  // copies of earlier chunks may still be writing the caller's buffer: let them finish before handing it back
-            (void)hipStreamSynchronize(c->copy_stream);
-            (void)hipStreamSynchronize(c->stream);
+            drain();
             return rc;
         }
-        RT_HIP(c, hipEventRecord(c->ev_chunk[k], c->stream));
-        RT_HIP(c, hipStreamWaitEvent(c->copy_stream, c->ev_chunk[k], 0));
-        RT_HIP(c, hipMemcpyAsync(out_host + off * bpp, static_cast<char*>(c->d_out) + off * bpp, (size_t)(r1 - r0) * w * bpp, hipMemcpyDeviceToHost, c->copy_stream));
-        if (hit_idx_host)
-            RT_HIP(c, hipMemcpyAsync(hit_idx_host + off, static_cast<char*>(c->d_hit) + off * 4, (size_t)(r1 - r0) * w * 4, hipMemcpyDeviceToHost, c->copy_stream));
+        hipError_t e;
+        if ((e = hipEventRecord(c->ev_chunk[k], st)) != hipSuccess || (e = hipStreamWaitEvent(c->copy_stream, c->ev_chunk[k], 0)) != hipSuccess ||
+            (e = hipMemcpyAsync(out_host + off * bpp, static_cast<char*>(c->d_out) + off * bpp, (size_t)(r1 - r0) * w * bpp, hipMemcpyDeviceToHost, c->copy_stream)) != hipSuccess ||
+            (hit_idx_host && (e = hipMemcpyAsync(hit_idx_host + off, static_cast<char*>(c->d_hit) + off * 4, (size_t)(r1 - r0) * w * 4, hipMemcpyDeviceToHost, c->copy_stream)) != hipSuccess)) {
+            drain();
+            return fail_hip(c, e, "chunked copy to the host");
+        }
+        last_of[k & 1u] = k;
     }
+    // end of the kernels of this call = both render streams have finished: the timing event sits on the ctx stream after a wait for the other
+    if (two_streams && last_of[1] < n_chunks) RT_HIP(c, hipStreamWaitEvent(c->stream, c->ev_chunk[last_of[1]], 0));
+    RT_HIP(c, hipEventRecord(c->ev_host_end, c->stream));
+    c->ev_end = c->ev_host_end;
     c->timed = true;
     RT_HIP(c, hipStreamSynchronize(c->copy_stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream2));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     return RT_OK;
 }
