@@ -836,6 +836,14 @@ inline bool is_general(const RenderArgs& a) { return a.depth > 1u || (a.flags & 
 #define RT_B 16
 #endif
 
+// Unused dynamic LDS requested at launch to cap the resident workgroups per CU of the general-ray kernels (sweep in profiles/r02_tuning.md)
+#ifndef RT_MASK_LDS_PAD
+#define RT_MASK_LDS_PAD 0
+#endif
+#ifndef RT_SHADE_LDS_PAD
+#define RT_SHADE_LDS_PAD 0
+#endif
+constexpr uint32_t kMaskLdsPad = RT_MASK_LDS_PAD, kShadeLdsPad = RT_SHADE_LDS_PAD;
 constexpr int kB = RT_B;       // spheres per wave vote in the primary loop (sweep in profiles/r01_tuning.md)
 #ifndef RT_SHADE_P
 #define RT_SHADE_P 2
@@ -887,7 +895,7 @@ namespace {
 // Resident workgroup slots of the current device for a persistent kernel (CUs x workgroups of 256 threads per CU), cached per
 // (kernel, device) in `cache` (one array per kernel; a benign race: concurrent callers compute the same value).
 template <typename Kernel>
-hipError_t resident_slots(Kernel kernel, uint32_t (&cache)[64], uint32_t& slots)
+hipError_t resident_slots(Kernel kernel, uint32_t (&cache)[64], uint32_t& slots, uint32_t dyn_lds = 0)
 {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -896,7 +904,7 @@ hipError_t resident_slots(Kernel kernel, uint32_t (&cache)[64], uint32_t& slots)
     if (cache[dev] == 0) {
         int cus = 0, per_cu = 0;
         if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
-        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kWaves * 64, 0)) != hipSuccess) return e;
+        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kWaves * 64, dyn_lds)) != hipSuccess) return e;
         if (cus <= 0 || per_cu <= 0) return hipErrorInvalidValue;
         cache[dev] = (uint32_t)cus * (uint32_t)per_cu;
     }
@@ -914,7 +922,7 @@ hipError_t primary_slots(uint32_t& slots)
 hipError_t mask_slots_of_device(uint32_t& slots)
 {
     static uint32_t cache[64] = {};
-    return resident_slots(shadow_mask_kernel<kMaskP, kShadowB, kShadowChunk>, cache, slots);
+    return resident_slots(shadow_mask_kernel<kMaskP, kShadowB, kShadowChunk>, cache, slots, kMaskLdsPad);
 }
 
 // Cut the band into the three tile sections of render_kernel and launch the persistent grid.
@@ -987,12 +995,12 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream, PhaseEvents
             const uint64_t worst_tiles = (npix + kWaves * 64 * kMaskP - 1) / (kWaves * 64 * kMaskP) * (uint64_t)args.n_lights;
             if (worst_tiles >= (1ull << 32)) return hipErrorInvalidValue;  // the tile queue counts in 32 bits
             const uint32_t grid = worst_tiles < mask_slots ? (uint32_t)worst_tiles : mask_slots;
-            hipLaunchKernelGGL((shadow_mask_kernel<kMaskP, kShadowB, kShadowChunk>), dim3(grid), dim3(kWaves * 64), 0, stream, a);
+            hipLaunchKernelGGL((shadow_mask_kernel<kMaskP, kShadowB, kShadowChunk>), dim3(grid), dim3(kWaves * 64), kMaskLdsPad, stream, a);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
         const bool timed = phases && it < kPhaseIters;
         if (timed && (e = hipEventRecord(phases->ev[2 + 2 * it], stream)) != hipSuccess) return e;
-        hipLaunchKernelGGL((shade_iter_kernel<kShadeP>), dim3(shade_wgs), dim3(kWaves * 64), 0, stream, a);
+        hipLaunchKernelGGL((shade_iter_kernel<kShadeP>), dim3(shade_wgs), dim3(kWaves * 64), kShadeLdsPad, stream, a);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if (timed) {
             if ((e = hipEventRecord(phases->ev[3 + 2 * it], stream)) != hipSuccess) return e;
