@@ -460,6 +460,7 @@ static int32_t take_tile_slot(rt_ctx* c, hipStream_t st, uint32_t& slot_out)
                 const hipError_t q = hipEventQuery(c->tile_slot_ev[i]);
                 if (q == hipSuccess) slot = i;
                 else if (q != hipErrorNotReady) return fail_hip(c, q, "hipEventQuery(tile slot)");
+                else (void)hipGetLastError();  // "not ready" is an answer, not an error: keep it out of the launch's hipGetLastError()
                 if (c->tile_slot_use[i] < c->tile_slot_use[lru]) lru = i;
             }
             if (slot == kTileSlots) {
