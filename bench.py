@@ -64,8 +64,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # BENCH_BACKEND=gloo: REHEARSAL of the multi-rank control flow on a box with fewer GPUs than ranks (ranks share the GPUs, the
+    # bands travel through host memory over gloo).  Everything a rank does except the link traffic runs for real — every rank's set-up
+    # and agreement collectives, the direct-RCCL attempt and the agreed fall-back, the band offsets of rank > 0 — and rank 0 checks the
+    # assembled frame against a single launch.  The JSON line is then NOT a benchmark result.
+    backend = os.environ.get("BENCH_BACKEND", "nccl")
+    if backend not in ("nccl", "gloo"):
+        raise SystemExit("BENCH_BACKEND must be nccl or gloo")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    cdev = dev if backend == "nccl" else torch.device("cpu")  # where the tensors of the control collectives live
     # BENCH_REHEARSE_DIST=1 runs the process-group / RCCL gather code path even with one rank (a 1-GPU box can then exercise it)
     use_dist = world > 1 or os.environ.get("BENCH_REHEARSE_DIST") == "1"
     if use_dist:
@@ -75,11 +84,14 @@ def main():
         os.environ.setdefault("WORLD_SIZE", str(world))
         # the band / frame buffers live for the whole run, so the process group need not pin them to its stream per call
         os.environ.setdefault("TORCH_NCCL_AVOID_RECORD_STREAMS", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     w, h, objs, lights = scenegen.config(args.config)
     m = capi.camera_transform(*capi.camera_default(), np.float32(w) / np.float32(h))
-    ctx = capi.Context(local_rank)
+    ctx = capi.Context(dev_index)
     ctx.scene_upload(objs, lights)
 
     y0, y1 = bands.band_rows(h, world, rank)
@@ -151,7 +163,7 @@ def main():
                     good = good and bool((frames[0][a_:b_] == r + 1 + ci).all())
             return good
 
-        rccl = rccl_gather.create_agreed(world, rank, local_rank, n_comms, device=dev, self_check=self_check)
+        rccl = rccl_gather.create_agreed(world, rank, dev_index, n_comms, device=cdev, self_check=self_check)
         band_bufs[0].zero_()
         if rccl is None:
             gather_mode = "torch"
@@ -165,7 +177,7 @@ def main():
             # client of the four hardware queues: keep frame streams + 1 within the number of streams the probe found to run
             # concurrently, so that no frame stream shares a queue with it ("the hang on record").
             wanted, usable, floor = min(slots, 3), found - 1, 1
-        slots = bands.agree_slots(wanted, usable, world, device=dev, floor=floor)
+        slots = bands.agree_slots(wanted, usable, world, device=cdev, floor=floor)
         while len(streams) < slots:
             streams.append(torch.cuda.Stream(dev))
         streams = streams[:slots]
@@ -177,6 +189,8 @@ def main():
                 views = bands.frame_gather_list(frames[s_], h, world) if rows_max * world == h else None  # (a band rehearsal has a short band)
                 gather_lists[s_] = views or [torch.empty_like(band_bufs[0]) for _ in range(world)]
         pipe = bands.GatherPipeline(world, rank, slots=slots, always_collective=True)
+        if backend == "gloo":
+            pipe = HostStagedGather(torch, dist, world, rank, h, frames)
     frame_no = [0]
     row_bytes = w * 4
     band_bytes = (y1 - y0) * row_bytes
@@ -194,7 +208,7 @@ def main():
                 ctx.render_rows_device(m, w, h, y0, y1, args.depth, flags, band_bufs[s].data_ptr(), 0, st.cuda_stream)
                 if ev is not None:
                     ev[1].record(st)
-                pipe.submit(k, band_bufs[s], gather_lists[s])  # the collective is ordered after st's render of this frame
+                pipe.submit(k, band_bufs[s], gather_lists[s] if backend == "nccl" else s)  # the collective is ordered after st's render of this frame
             return
         render_part(s, st, ev)
         if gather_mode == "rccl":  # stream order: render k -> gather k -> (slots frames later) render k + slots
@@ -282,18 +296,26 @@ def main():
             gather_part(k % slots, streams[k % slots])
         fence()
         t_g1 = time.perf_counter()
-        d = torch.tensor([t_r1 - t_r0, t_g1 - t_r1], dtype=torch.float64, device=dev)
+        d = torch.tensor([t_r1 - t_r0, t_g1 - t_r1], dtype=torch.float64, device=cdev)
         dist.all_reduce(d, op=dist.ReduceOp.MAX)
         peer_bytes = bands.max_band_rows(h, world) * row_bytes if world > 1 else band_bytes
         diag = {"render_only_us_per_step": float(d[0]) / n_diag * 1e6, "gather_only_us_per_step": float(d[1]) / n_diag * 1e6,
                 "gather_only_GBps_per_peer_link": peer_bytes / (float(d[1]) / n_diag) / 1e9,
                 "note": "%d steps each, after the timed region, same streams; the fence (device sync + barrier) is inside both figures" % n_diag}
 
-    tmax = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=cdev)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed_max, kern_ms_max = float(tmax[0]), float(tmax[1])
 
+    frame_check = None
+    if backend == "gloo" and use_dist and rank == 0 and gather_mode == "torch":
+        whole = torch.zeros((h, w, 4), dtype=torch.uint8, device=dev)
+        ctx.render_rows_device(m, w, h, 0, h, args.depth, flags, whole.data_ptr(), 0, streams[0].cuda_stream)
+        streams[0].synchronize()
+        frame_check = all(bool(torch.equal(f_, whole)) for f_ in frames)
+        if not frame_check:
+            raise SystemExit("rehearsal: the frame assembled from the ranks' bands differs from the single launch")
     if rank == 0:
         rays_per_step = w * h if rehearse_band <= 1 else (y1 - y0) * w
         value = rays_per_step * args.steps / elapsed_max
@@ -364,6 +386,9 @@ def main():
         out["roofline"]["traffic"], out["roofline"]["traffic_note"] = pmc_traffic(args.config, args.depth, args.shadows, dom[0])
         if diag is not None:
             out["diagnostics"] = diag
+        if backend == "gloo" and use_dist:
+            out["rehearsal"] = ("BENCH_BACKEND=gloo: %d ranks sharing %d GPU(s), bands gathered through host memory; control-flow rehearsal, not a result; "
+                                "assembled frames equal the single launch: %s" % (world, torch.cuda.device_count(), frame_check))
         if rehearse_band > 1:
             out["rehearsal"] = "one rank rendering the band of 1/%d of the frame: host issue-rate probe, not a result" % rehearse_band
         if world == 1 and not args.no_cpu_baseline:
@@ -375,6 +400,32 @@ def main():
         comm.close()
     if use_dist:
         dist.destroy_process_group()
+
+
+class HostStagedGather:
+    """BENCH_BACKEND=gloo only: the interface of bands.GatherPipeline with the bands staged through host memory (gloo has no device
+    gather).  submit(k, band, slot): wait for the render, copy the band to the host, gather, rank 0 copies every band into its rows of
+    frames[slot].  Synchronous: a rehearsal of the control flow, not of the overlap."""
+
+    def __init__(self, torch, dist, world, rank, h, frames):
+        self.torch, self.dist, self.world, self.rank, self.h, self.frames = torch, dist, world, rank, h, frames
+
+    def begin(self, k):
+        return 0
+
+    def submit(self, k, band, slot):
+        from raytracing_amd import bands as _b
+        self.torch.cuda.current_stream().synchronize()
+        host = band.cpu()
+        parts = [self.torch.empty_like(host) for _ in range(self.world)] if self.rank == 0 else None
+        self.dist.gather(host, gather_list=parts, dst=0)
+        if self.rank == 0:
+            for r in range(self.world):
+                a, b = _b.band_rows(self.h, self.world, r)
+                self.frames[slot][a:b].copy_(parts[r][: b - a])
+
+    def drain(self):
+        pass
 
 
 def pick_concurrent_streams(torch, dev, n, candidates=16, pool=None):

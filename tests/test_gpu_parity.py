@@ -721,3 +721,31 @@ def test_multi_device_parts_with_fake_rccl():
     env = dict(os.environ, RT_RCCL_LIB=fake, RT_MULTI_SPLIT_PARTS="1")
     r = subprocess.run([sys.executable, os.path.join(here, "multi_parts_worker.py")], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_bench_multi_rank_control_flow_rehearsal(ranks):
+    """bench.py with more than one rank, for real, on the one-GPU box: BENCH_BACKEND=gloo lets the ranks share the GPU and gathers the
+    bands through host memory, everything else is the code a multi-GPU run executes — every rank's set-up, the collective-safe attempt
+    at the direct RCCL gather (real RCCL refuses two ranks on one device: BOTH ranks must report it and agree on the fall-back, nobody
+    hangs), the slot agreement, the band offsets of rank > 0, the timing reduction.  Rank 0 compares every assembled frame with a
+    single launch.  3 ranks: uneven bands (2160 / 3 = 720 is even, so the height is not the point; the rank count is)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(GOLDEN), ".."))
+    port = 29650 + ranks
+    env = dict(os.environ, BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(ranks), "--steps", "12", "--warmup", "2"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(line) == 1, r.stdout[-2000:]
+    out = json.loads(line[0])
+    assert out["n_gpus"] == ranks and out["steps"] == 12 and out["scaling"] == "strong"
+    assert "assembled frames equal the single launch: True" in out["rehearsal"]
+    assert "torch.distributed.gather" in out["config"]["parallelism"]  # the agreed fall-back
+    assert 0 < out["roofline"]["frac"] < 1
+    for k in range(ranks):
+        assert ("rank %d: direct RCCL gather unavailable" % k) in r.stderr
