@@ -204,10 +204,8 @@ def main():
             with torch.cuda.stream(st):
                 pipe.begin(k)  # stream-level wait (on st) until the gather that last read band_bufs[s] is done
                 if ev is not None:
-                    ev[0].record(st)
+                    ev.record(st)
                 ctx.render_rows_device(m, w, h, y0, y1, args.depth, flags, band_bufs[s].data_ptr(), 0, st.cuda_stream)
-                if ev is not None:
-                    ev[1].record(st)
                 pipe.submit(k, band_bufs[s], gather_lists[s] if backend == "nccl" else s)  # the collective is ordered after st's render of this frame
             return
         render_part(s, st, ev)
@@ -219,10 +217,8 @@ def main():
         in_place = gather_mode == "rccl" and rank == 0 and rehearse_band <= 1
         d_out = frames[s].data_ptr() + y0 * row_bytes if in_place else band_bufs[s].data_ptr()
         if ev is not None:
-            ev[0].record(st)
+            ev.record(st)
         ctx.render_rows_device(m, w, h, y0, y1, args.depth, flags, d_out, 0, st.cuda_stream)
-        if ev is not None:
-            ev[1].record(st)
 
     def gather_part(s, st):
         comm = rccl[s % n_comms]
@@ -251,19 +247,26 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    # HIP events on the launch stream over the timed region: ONE per step, recorded in front of the step's launch (and one behind the
+    # last), so the duration of launch k is event k -> event k + 1 on that stream.  An event is a packet of its own between two
+    # kernels and costs ~4 us of GPU timeline: two per launch plus the two the library used to record cost 3 % of a C3 frame
+    # (profiles/r02_tuning.md); this way the measured duration also holds the launch gap (it can only overstate the kernel).
+    events = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + slots)]
     phase_ms = [0.0, 0.0, 0.0]
     fence()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(events[k])
+    for s_ in range(slots):  # the closing event of every stream's last step
+        events[args.steps + s_].record(streams[(args.steps + s_) % slots])
     t_issued = time.perf_counter()
     fence()
     t1 = time.perf_counter()
     print("rank %d: host issued %d steps in %.3f ms (%.1f us per step), all done after %.3f ms" %
           (rank, args.steps, (t_issued - t0) * 1e3, (t_issued - t0) * 1e6 / max(1, args.steps), (t1 - t0) * 1e3), file=sys.stderr)
     elapsed = t1 - t0
-    kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)  # HIP events on the launch stream
+    # step k runs on stream k % slots; the next event on that stream is the one of step k + slots (or the closing one)
+    kern_ms = sum(events[k].elapsed_time(events[k + slots]) for k in range(args.steps)) / max(1, args.steps)
 
     # General path: per-kernel durations of a launch come from the library's own HIP events between its kernels (rt_last_phase_ms):
     # a few more steps after the timed region, one at a time, averaged.  Also the number of hit records (= rays the general kernels trace).
@@ -271,7 +274,7 @@ def main():
     if general:
         n_ph = max(1, min(args.steps, 10))
         for _ in range(n_ph):
-            ctx.render_rows_device(m, w, h, y0, y1, args.depth, flags, band_bufs[0].data_ptr(), 0, streams[0].cuda_stream)
+            ctx.render_rows_device(m, w, h, y0, y1, args.depth, flags | capi.RT_TIMED, band_bufs[0].data_ptr(), 0, streams[0].cuda_stream)
             p_ms = ctx.last_phase_ms()
             for i_ in range(3):
                 phase_ms[i_] += p_ms[i_] / n_ph
@@ -372,7 +375,7 @@ def main():
                          "kernel": dom[0] if not wall_based else "all kernels of this rank's step",
                          "kernel_ms": dom_ms, "kernel_ms_max_over_ranks": kern_ms_max if not general else None,
                          "duration_source": ("wall clock of the step (max over ranks): %d frames in flight on %d streams, per-launch event durations would overlap" % (slots, slots))
-                         if wall_based else ("HIP events on the launch stream around every timed launch" if not general else
+                         if wall_based else ("HIP events on the launch stream, one in front of every timed launch (duration = event k -> event k + 1: kernel + launch gap)" if not general else
                                              "HIP events the library records between its kernels (rt_last_phase_ms), %d launches after the timed region" % max(1, min(args.steps, 10))),
                          "flops_counted": dom[4] if not wall_based else "; ".join(k_[4] for k_ in kernels)},
         }

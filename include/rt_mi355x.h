@@ -42,6 +42,9 @@ extern "C" {
 /* rt_render* flags */
 #define RT_SHADOWS 1u  /* EXTENSION (no reference counterpart): point lights are occluded by elements, see DESIGN.md */
 #define RT_OUT_RGB8 2u /* write 3 B/pixel exactly like Framebuffer.pixels (display.rs:16-20,50-57); default RGBA8, A=255 */
+#define RT_TIMED 4u    /* rt_render_rows_device only: record HIP events around the launch (and between its kernels) for rt_last_kernel_ms /
+                          rt_last_phase_ms.  Off by default: an event costs ~4 us of GPU time between back-to-back launches (1.3 % of a
+                          C3 frame for the pair).  The blocking host-output entry points always time their kernels; ignored elsewhere. */
 
 /* shadow-ray acceptance window of the RT_SHADOWS extension: occluded iff RT_SHADOW_EPS < t < distance(light) */
 #define RT_SHADOW_EPS 1.0e-3f
@@ -170,14 +173,16 @@ int32_t rt_render_rows_device_noalloc(rt_ctx* ctx, const float m[16], uint32_t w
 int32_t rt_host_alloc(rt_ctx* ctx, size_t bytes, void** out);
 int32_t rt_host_free(rt_ctx* ctx, void* host_ptr);
 
-/* Elapsed GPU time (ms, hipEvent) of the kernels of the most recent rt_render* on this ctx; synchronises on its end event. */
+/* Elapsed GPU time (ms, hipEvent) of the kernels of the most recent rt_render / rt_render_rows, or rt_render_rows_device launched with
+   RT_TIMED, on this ctx; synchronises on its end event.  RT_ERR_INVALID if the most recent launch was not timed. */
 int32_t rt_last_kernel_ms(rt_ctx* ctx, float* ms);
 
 /*
  * Per-kernel GPU time (ms, hipEvent) of the most recent launch with depth > 1 or RT_SHADOWS on this ctx (the last row chunk, for the
  * host-output entry points): ms[0] = primary kernel that emits the hit records, ms[1] = shadow_mask_kernel launches (RT_SHADOWS; with
  * the clears of their occlusion words), ms[2] = shade_iter_kernel launches (shading + bounce trace), summed over the first 4
- * iterations of renderer.rs:46.  RT_ERR_INVALID if the most recent launch was primary-only.  Synchronises on the launch's end.
+ * iterations of renderer.rs:46.  RT_ERR_INVALID if the most recent launch was primary-only or an rt_render_rows_device without RT_TIMED.
+ * Synchronises on the launch's end.
  */
 int32_t rt_last_phase_ms(rt_ctx* ctx, float ms[3]);
 

@@ -22,6 +22,7 @@ RT_AMBIENT = 1
 
 RT_SHADOWS = 1
 RT_OUT_RGB8 = 2
+RT_TIMED = 4  # rt_render_rows_device: record the events rt_last_kernel_ms / rt_last_phase_ms read
 RT_SHADOW_EPS = 1.0e-3
 RT_NOALLOC_SCRATCH_BYTES = 32 << 20
 

@@ -50,11 +50,14 @@ struct rt_ctx {
     // tile-queue counters of the persistent primary kernel: a ring of slots (64 B apart), one per launch in flight
     uint32_t* d_tile_ctr = nullptr;
     hipStream_t tile_slot_stream[16] = {};  // slot i was last used by this stream (launches of one stream execute in order and can share it)
-    hipEvent_t tile_slot_ev[16] = {};       // recorded after the last launch that used slot i: the slot is free again once it has completed
+    hipEvent_t tile_slot_ev[16] = {};       // recorded after the last launch that used slot i (once slot events are on): the slot is free again once it has completed
+    bool tile_slot_ev_valid[16] = {};       // that event really follows the slot's last launch
+    bool slot_events_on = false;            // a context that has seen few streams records nothing per launch (an event costs ~4 us of GPU timeline between launches)
     uint64_t tile_slot_use[16] = {};        // use clock of that launch (least recently used slot is the one recycled)
     uint64_t use_clock = 0;
     uint32_t tile_slots_used = 0;
-    hipEvent_t ev_end = nullptr;            // end of the most recent launch (one of tile_slot_ev), for rt_last_kernel_ms
+    hipEvent_t ev_end = nullptr;            // end of the most recent TIMED launch (ev_dev_end / ev_host_end / ev_multi_end), for rt_last_kernel_ms
+    hipEvent_t ev_dev_end = nullptr;        // end of the most recent rt_render_rows_device launch with RT_TIMED
     // launches with depth > 1 or RT_SHADOWS share d_rec: each one waits (stream-level) for the previous one
     hipEvent_t ev_general = nullptr;
     PhaseEvents phases = {};                // per-kernel timing of the most recent general launch (rt_last_phase_ms)
@@ -216,7 +219,8 @@ int32_t rt_ctx_create(rt_ctx** out, int32_t device_id)
     DeviceGuard guard(device_id);
     if ((e = guard.status) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreateWithFlags(&c->ev_general, hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev_dev_end)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->ev_general, hipEventDisableTiming)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess || (e = hipEventCreate(&c->ev_host_end)) != hipSuccess ||
         (e = hipMalloc(reinterpret_cast<void**>(&c->d_tile_ctr), kTileSlots * 64)) != hipSuccess ||
         (e = hipMemset(c->d_tile_ctr, 0, kTileSlots * 64)) != hipSuccess) {
@@ -237,7 +241,7 @@ int32_t rt_ctx_create(rt_ctx** out, int32_t device_id)
             return rc;
         }
     for (uint32_t i = 0; i < kTileSlots; ++i)
-        if ((e = hipEventCreate(&c->tile_slot_ev[i])) != hipSuccess) {
+        if ((e = hipEventCreateWithFlags(&c->tile_slot_ev[i], hipEventDisableTiming)) != hipSuccess) {
             int32_t rc = fail_hip(nullptr, e, "context setup (slot events)");
             rt_ctx_destroy(c);
             return rc;
@@ -330,6 +334,7 @@ int32_t rt_ctx_destroy(rt_ctx* c)
     if (c->d_band) (void)hipFree(c->d_band);
     if (c->d_tile_ctr) (void)hipFree(c->d_tile_ctr);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev_dev_end) (void)hipEventDestroy(c->ev_dev_end);
     if (c->ev_general) (void)hipEventDestroy(c->ev_general);
     for (hipEvent_t e : c->tile_slot_ev)
         if (e) (void)hipEventDestroy(e);
@@ -432,7 +437,7 @@ static int32_t check_render_args(rt_ctx* c, const float* m, uint32_t w, uint32_t
     if (depth == 0) return fail(c, RT_ERR_INVALID, "depth must be >= 1 (the reference computes depth - 1 on usize, renderer.rs:36)");
     if (w == 0 || h == 0) return fail(c, RT_ERR_INVALID, "empty frame");
     if (y0 > y1 || y1 > h) return fail(c, RT_ERR_INVALID, "row band outside the frame");
-    if (flags & ~(RT_SHADOWS | RT_OUT_RGB8)) return fail(c, RT_ERR_INVALID, "unknown flag bits");
+    if (flags & ~(RT_SHADOWS | RT_OUT_RGB8 | RT_TIMED)) return fail(c, RT_ERR_INVALID, "unknown flag bits");
     if ((uint64_t)w * (uint64_t)h > (1ull << 31)) return fail(c, RT_ERR_TOO_LARGE, "frame larger than 2^31 pixels");
     return RT_OK;
 }
@@ -444,8 +449,13 @@ static int32_t check_render_args(rt_ctx* c, const float* m, uint32_t w, uint32_t
 enum class ScratchKind { kContext, kStatic };
 
 // The tile-queue counters of a launch on `st`: kernels that can run concurrently must not share a queue, kernels of one stream run in
-// order and can.  Slots are recycled: same stream first, then a slot that was never used or whose last launch has completed, else the
-// least recently used slot — and `st` then waits (stream-level, the host does not block) for that slot's last launch.
+// order and can.  Slots are recycled: same stream first; then a free slot; with the table full, a slot whose last launch has completed
+// (its event), else the least recently used slot — and `st` then waits (stream-level, the host does not block) for that slot's last
+// launch.  Events cost GPU time between launches (~4 us each), so a context records them only once it has seen more than half the
+// table's worth of distinct streams (a host that churns streams); slots last used before that have no event: if one of those must be
+// recycled the device is synchronised once and the whole table is free again.
+static constexpr uint32_t kSlotEventsFrom = 8;
+
 static int32_t take_tile_slot(rt_ctx* c, hipStream_t st, uint32_t& slot_out)
 {
     uint32_t slot = kTileSlots;
@@ -454,21 +464,33 @@ static int32_t take_tile_slot(rt_ctx* c, hipStream_t st, uint32_t& slot_out)
     if (slot == kTileSlots) {
         if (c->tile_slots_used < kTileSlots) {
             slot = c->tile_slots_used++;
+            if (c->tile_slots_used > kSlotEventsFrom) c->slot_events_on = true;
         } else {
             uint32_t lru = 0;
+            bool unknown = false;
             for (uint32_t i = 0; i < kTileSlots && slot == kTileSlots; ++i) {
+                if (!c->tile_slot_ev_valid[i]) { unknown = true; continue; }
                 const hipError_t q = hipEventQuery(c->tile_slot_ev[i]);
                 if (q == hipSuccess) slot = i;
                 else if (q != hipErrorNotReady) return fail_hip(c, q, "hipEventQuery(tile slot)");
                 else (void)hipGetLastError();  // "not ready" is an answer, not an error: keep it out of the launch's hipGetLastError()
                 if (c->tile_slot_use[i] < c->tile_slot_use[lru]) lru = i;
             }
-            if (slot == kTileSlots) {
-                slot = lru;
+            if (slot == kTileSlots && unknown) {
+                RT_HIP(c, hipDeviceSynchronize());  // once: slots whose last launch predates the events; everything is idle afterwards
+                for (uint32_t i = 0; i < kTileSlots; ++i) {
+                    c->tile_slot_stream[i] = nullptr;
+                    c->tile_slot_ev_valid[i] = false;
+                }
+                c->tile_slots_used = 1;
+                slot = 0;
+            } else if (slot == kTileSlots) {
+                slot = c->tile_slot_ev_valid[lru] ? lru : 0;
                 RT_HIP(c, hipStreamWaitEvent(st, c->tile_slot_ev[slot], 0));
             }
         }
         c->tile_slot_stream[slot] = st;
+        c->tile_slot_ev_valid[slot] = false;
     }
     c->tile_slot_use[slot] = ++c->use_clock;
     slot_out = slot;
@@ -477,7 +499,7 @@ static int32_t take_tile_slot(rt_ctx* c, hipStream_t st, uint32_t& slot_out)
 
 // Enqueue the kernels of the band [y0, y1) on `st` (arguments already checked, ctx's device current).
 static int32_t enqueue_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t depth, uint32_t flags,
-                            void* d_out, void* d_hit_idx, hipStream_t st, ScratchKind kind = ScratchKind::kContext)
+                            void* d_out, void* d_hit_idx, hipStream_t st, ScratchKind kind = ScratchKind::kContext, bool time_it = true)
 {
     RenderArgs a;
     std::memcpy(a.m, m, sizeof(a.m));
@@ -543,13 +565,15 @@ static int32_t enqueue_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h
         if (need_state) a.rec_state = reinterpret_cast<float*>(rec_base + 16 + 3 * plane);
         if (occ_words) a.rec_occ = reinterpret_cast<uint32_t*>(rec_base + 16 + (3 + (need_state ? 9 : 0)) * plane);
     }
-    const bool time_phases = general && kind == ScratchKind::kContext;
-    if (time_phases) c->phases_valid = false;
+    const bool time_phases = general && kind == ScratchKind::kContext && time_it;
+    if (kind == ScratchKind::kContext) c->phases_valid = false;
     RT_HIP(c, launch_render(a, st, time_phases ? &c->phases : nullptr));
     if (kind == ScratchKind::kContext) {
         c->phases_valid = time_phases && c->phases.iters > 0;
-        RT_HIP(c, hipEventRecord(c->tile_slot_ev[slot], st));
-        c->ev_end = c->tile_slot_ev[slot];
+        if (c->slot_events_on) {
+            RT_HIP(c, hipEventRecord(c->tile_slot_ev[slot], st));
+            c->tile_slot_ev_valid[slot] = true;
+        }
         if (general) {
             RT_HIP(c, hipEventRecord(c->ev_general, st));
             c->general_pending = true;
@@ -628,20 +652,24 @@ int32_t rt_render_rows_device(rt_ctx* c, const float m[16], uint32_t w, uint32_t
     if (rc != RT_OK) return rc;
     if (y1 > y0 && !d_out) return fail(c, RT_ERR_INVALID, "output pointer is null");
     RT_DEVICE(c);
+    const bool time_it = (flags & RT_TIMED) != 0u;
+    flags &= ~RT_TIMED;
     if (c->multi) {
         hipStream_t st = stream ? static_cast<hipStream_t>(stream) : c->parts[0]->stream;
-        RT_HIP(c, hipEventRecord(c->ev0, st));
+        if (time_it) RT_HIP(c, hipEventRecord(c->ev0, st));
         if (y1 > y0 && (rc = multi_enqueue(c, m, w, h, y0, y1, depth, flags, d_out, d_hit_idx, st)) != RT_OK) return rc;
-        RT_HIP(c, hipEventRecord(c->ev_multi_end, st));
+        if (time_it) RT_HIP(c, hipEventRecord(c->ev_multi_end, st));
         c->ev_end = c->ev_multi_end;
-        c->timed = true;
+        c->timed = time_it;
         return RT_OK;
     }
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : c->stream;
-    RT_HIP(c, hipEventRecord(c->ev0, st));
-    rc = enqueue_rows(c, m, w, h, y0, y1, depth, flags, d_out, d_hit_idx, st);
+    if (time_it) RT_HIP(c, hipEventRecord(c->ev0, st));
+    rc = enqueue_rows(c, m, w, h, y0, y1, depth, flags, d_out, d_hit_idx, st, ScratchKind::kContext, time_it);
     if (rc != RT_OK) return rc;
-    c->timed = true;
+    if (time_it) RT_HIP(c, hipEventRecord(c->ev_dev_end, st));
+    c->ev_end = c->ev_dev_end;
+    c->timed = time_it;
     return RT_OK;
 }
 
@@ -655,7 +683,7 @@ int32_t rt_render_rows_device_noalloc(rt_ctx* c, const float m[16], uint32_t w, 
     if (!c->noalloc_scratch) return fail(c, RT_ERR_HIP, "the scratch array of this device was not resolved at rt_ctx_create");
     RT_DEVICE(c);
     hipStream_t st = stream ? static_cast<hipStream_t>(stream) : c->stream;
-    return enqueue_rows(c, m, w, h, y0, y1, depth, flags, d_out, d_hit_idx, st, ScratchKind::kStatic);
+    return enqueue_rows(c, m, w, h, y0, y1, depth, flags & ~RT_TIMED, d_out, d_hit_idx, st, ScratchKind::kStatic, false);
 }
 
 int32_t rt_render_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t depth, uint32_t flags,
@@ -665,6 +693,7 @@ int32_t rt_render_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h, uin
     if (rc != RT_OK) return rc;
     if (y1 == y0) return RT_OK;
     if (!out_host) return fail(c, RT_ERR_INVALID, "output pointer is null");
+    flags &= ~RT_TIMED;  // the host-output entry points always time their kernels (two events per blocking call)
     RT_DEVICE(c);
     const size_t npix = (size_t)(y1 - y0) * w;
     const size_t bytes = npix * ((flags & RT_OUT_RGB8) ? 3 : 4);
@@ -797,7 +826,7 @@ int32_t rt_host_free(rt_ctx* c, void* p)
 int32_t rt_last_phase_ms(rt_ctx* c, float ms[3])
 {
     if (!c || !ms) return RT_ERR_INVALID;
-    if (!c->phases_valid) return fail(c, RT_ERR_INVALID, "the most recent launch of this context was not a general one (depth > 1 or RT_SHADOWS)");
+    if (!c->phases_valid) return fail(c, RT_ERR_INVALID, "the most recent launch of this context was not a timed general one (depth > 1 or RT_SHADOWS; rt_render_rows_device needs RT_TIMED)");
     RT_DEVICE(c);
     const PhaseEvents& p = c->phases;
     RT_HIP(c, hipEventSynchronize(p.ev[1 + 2 * p.iters]));
@@ -816,7 +845,7 @@ int32_t rt_last_phase_ms(rt_ctx* c, float ms[3])
 int32_t rt_last_kernel_ms(rt_ctx* c, float* ms)
 {
     if (!c || !ms) return RT_ERR_INVALID;
-    if (!c->timed) return fail(c, RT_ERR_INVALID, "no render has been enqueued on this context");
+    if (!c->timed) return fail(c, RT_ERR_INVALID, "the most recent launch of this context was not timed (rt_render_rows_device needs RT_TIMED)");
     RT_DEVICE(c);
     RT_HIP(c, hipEventSynchronize(c->ev_end));
     RT_HIP(c, hipEventElapsedTime(ms, c->ev0, c->ev_end));

@@ -21,7 +21,7 @@ with capi.Context(0) as ctx:
     e0.record(st)
     t[0] = time.perf_counter()
     for i in range(n):
-        ctx.render_rows_device(m, w, h, 945, 945 + rows, 1, 0, out.data_ptr(), 0, st.cuda_stream)
+        ctx.render_rows_device(m, w, h, 945, 945 + rows, 1, capi.RT_TIMED, out.data_ptr(), 0, st.cuda_stream)
         t[i + 1] = time.perf_counter()
     e1.record(st)
     e1.synchronize()

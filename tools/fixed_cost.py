@@ -15,7 +15,7 @@ with capi.Context(0) as ctx:
             out = torch.zeros((rows, w, 4), dtype=torch.uint8, device="cuda")
             ms = []
             for _ in range(12):
-                ctx.render_rows_device(m, w, h, 945 if rows < h else 0, (945 if rows < h else 0) + rows, 1, 0, out.data_ptr())
+                ctx.render_rows_device(m, w, h, 945 if rows < h else 0, (945 if rows < h else 0) + rows, 1, capi.RT_TIMED, out.data_ptr())
                 ms.append(ctx.last_kernel_ms())
             res.append(sorted(ms[2:])[5])
         print("N=%5d  band270 %.4f ms   full %.4f ms" % (n, res[0], res[1]))

@@ -18,7 +18,7 @@ y0, y1 = (0, h) if a.rows is None else map(int, a.rows.split(":"))
 m = capi.camera_transform(*capi.camera_default(), np.float32(w) / np.float32(h))
 import torch
 out = torch.zeros(((y1 - y0), w, 4), dtype=torch.uint8, device="cuda")
-flags = (capi.RT_SHADOWS if a.shadows else 0) | (capi.RT_OUT_RGB8 if a.rgb8 else 0)
+flags = (capi.RT_SHADOWS if a.shadows else 0) | (capi.RT_OUT_RGB8 if a.rgb8 else 0) | capi.RT_TIMED
 with capi.Context(0) as ctx:
     ctx.scene_upload(objs, lights)
     import time

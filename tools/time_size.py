@@ -13,7 +13,7 @@ with capi.Context(0) as ctx:
         out = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
         ms = []
         for _ in range(12):
-            ctx.render_rows_device(m, w, 2160, 1000 - h // 2 if h < 2160 else 0, (1000 - h // 2 if h < 2160 else 0) + h, 1, 0, out.data_ptr())
+            ctx.render_rows_device(m, w, 2160, 1000 - h // 2 if h < 2160 else 0, (1000 - h // 2 if h < 2160 else 0) + h, 1, capi.RT_TIMED, out.data_ptr())
             ms.append(ctx.last_kernel_ms())
         t = sorted(ms[2:])[len(ms[2:]) // 2]
         wgs = (w // 64) * ((h + 15) // 16)

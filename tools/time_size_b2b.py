@@ -20,7 +20,7 @@ with capi.Context(0) as ctx:
             e0.record(st)
             for _ in range(n):
                 # rows of a taller virtual frame keep the same per-row content statistics irrelevant here: cost per (pixel, sphere) is uniform
-                ctx.render_rows_device(m, w, max(h, 2160), 0, h, 1, 0, out.data_ptr(), 0, st.cuda_stream)
+                ctx.render_rows_device(m, w, max(h, 2160), 0, h, 1, capi.RT_TIMED, out.data_ptr(), 0, st.cuda_stream)
             e1.record(st)
             e1.synchronize()
         t = e0.elapsed_time(e1) / n
