@@ -581,6 +581,23 @@ def test_many_launches_in_flight_on_several_streams(oracle):
         torch.cuda.synchronize()
         for i, b in enumerate(bufs):
             _assert_same(b.cpu().numpy(), ref, f"24 streams at once, stream {i}")
+    # the same on a FRESH context: its first 8 streams are launched without slot events (nothing can need recycling yet), so the 17th
+    # busy stream finds slots it knows nothing about and the table is reset after one device synchronisation (take_tile_slot)
+    with capi.Context(0) as ctx:
+        ctx.scene_upload(objs, lights)
+        for b in bufs:
+            b.zero_()
+        for rep in range(2):
+            for st, b in zip(many, bufs):
+                ctx.render_rows_device(m, w, h, 0, 1000, 1, 0, b.data_ptr(), 0, st.cuda_stream)
+        torch.cuda.synchronize()
+        for i, b in enumerate(bufs):
+            _assert_same(b.cpu().numpy(), ref, f"fresh context, 24 streams at once, stream {i}")
+        with pytest.raises(capi.RtError) as e:  # nothing was timed: the device entry point records events only with RT_TIMED
+            ctx.last_kernel_ms()
+        assert e.value.code == capi.RT_ERR_INVALID
+        ctx.render_rows_device(m, w, h, 0, 1000, 1, capi.RT_TIMED, bufs[0].data_ptr(), 0, many[0].cuda_stream)
+        assert 0.05 < ctx.last_kernel_ms() < 50.0
 
 
 def test_general_launches_on_different_streams_are_ordered(oracle):
