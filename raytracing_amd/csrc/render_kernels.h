@@ -21,7 +21,11 @@ struct RenderArgs {
     const int32_t* always;  // n_always
     const float4* lpos;     // n_lights
     const float4* lcol;     // n_lights
-    const float4* lfilt;        // n_lights * n_pad: per-light shadow filter constants
+    const float4* lfilt;        // n_lights * n_pad: per-light shadow filter constants in SPATIAL order, w = P2 of the member test
+    const float4* lclA;         // n_lights * n_pad / 16: per cluster of 16 entries (cone axis x, y, z, dmin)
+    const float4* lclB;         // n_lights * n_pad / 16: (cos, sin of the cluster's half-angle, 0, 0)
+    const int32_t* order;       // n_pad: element at spatial position j, -1 = padding
+    const int32_t* rank;        // n_pad: spatial position of element i (sort key of the hit records)
     const int32_t* lalways;     // per-light always-test lists, concatenated
     const int32_t* lalways_off; // n_lights + 1
     const float4* pln;          // n_pad: (nx, ny, nz, 1) for RT_PLANE elements (extension), 0 for spheres
@@ -31,7 +35,7 @@ struct RenderArgs {
     uint8_t* out;           // band rows, 4 or 3 B/pixel
     int32_t* hit_idx;       // nullable
     // dense hit records (library-owned scratch, only for depth > 1 or RT_SHADOWS): one counter + capacity >= band pixels
-    uint32_t* rec_count;
+    uint32_t* rec_count;  // [0] = records emitted by the primary kernel, [1] = live records of the current iteration (sort_scan_kernel)
     uint32_t* rec_pix;
     int32_t* rec_idx;
     float* rec_t;
@@ -39,6 +43,8 @@ struct RenderArgs {
     uint32_t iter;        // iteration of renderer.rs:46 the general-ray kernels work on (set by launch_render)
     float* rec_state;     // depth > 1: 9 planes of rec_cap floats (origin, direction, colour of the bounce ray); else null
     uint32_t* rec_occ;    // RT_SHADOWS: ceil(n_lights / 32) planes of rec_cap words, occlusion bit per (record, light); else null
+    uint32_t* rec_perm;   // RT_SHADOWS: rec_cap words, the live records of this iteration in spatial order (rec_count[1] entries); else null
+    uint32_t* sort_bins;  // RT_SHADOWS: n + 1 words, histogram / running offsets of the record sort; else null
     // tile queue of the persistent primary kernel: tile_ctr[0] = next tile, tile_ctr[1] = workgroups that have left (library-owned,
     // zero between launches); the rest is filled in by launch_render
     uint32_t* tile_ctr;
@@ -78,8 +84,9 @@ hipError_t clear_scratch_words(uint32_t* q, uint32_t nq, hipStream_t stream);
 // True if launch_render needs the rec_* scratch buffers for these args (depth > 1 or RT_SHADOWS).
 bool render_needs_records(const RenderArgs& args);
 
-// Which optional scratch planes these args need beside count/pix/idx/t: rec_state (9 float planes) and rec_occ (occ_words planes).
-void render_scratch_layout(const RenderArgs& args, bool& need_state, uint32_t& occ_words);
+// Which optional scratch these args need beside count/pix/idx/t: rec_state (9 float planes), rec_occ (occ_words planes) and, with
+// occ_words > 0, one more plane (rec_perm) plus bin_words words of sort bins.
+void render_scratch_layout(const RenderArgs& args, bool& need_state, uint32_t& occ_words, uint32_t& bin_words);
 
 // Name of the kernel variant launch_render picks for these args (for profiles / bench output).
 const char* render_kernel_name(const RenderArgs& args);

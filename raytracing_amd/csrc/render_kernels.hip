@@ -27,14 +27,14 @@ constexpr int kLX = 16;      // lanes of a wave along x
 constexpr int kLY = 4;       // lanes of a wave along y
 constexpr int kWaves = 4;    // waves per workgroup, side by side along x
 constexpr int kChunk = 1024; // spheres staged in LDS per pass (16 KiB)
-#ifndef RT_SHADOW_CHUNK
-#define RT_SHADOW_CHUNK 2048
+#ifndef RT_SHADOW_CAP
+#define RT_SHADOW_CAP 256
 #endif
 #ifndef RT_SHADOW_B
 #define RT_SHADOW_B 8
 #endif
-constexpr int kShadowB = RT_SHADOW_B;  // spheres per wave vote in the shadow loops
-constexpr int kShadowChunk = RT_SHADOW_CHUNK;  // spheres per pass in the per-light shadow loops of shadow_mask_kernel
+constexpr int kShadowB = RT_SHADOW_B;      // spheres per wave vote in the shadow loop
+constexpr int kShadowCap = RT_SHADOW_CAP;  // entries of the per-wave sphere list of shadow_mask_kernel (16 B each in LDS)
 
 // math/vec3.rs:118-155 — (xx + yy) + (zz + 0): every product and sum individually rounded
 __device__ __forceinline__ float dot3_ref(float ax, float ay, float az, float bx, float by, float bz)
@@ -253,105 +253,6 @@ __device__ __forceinline__ void trace_general(const RenderArgs& A, float* s_gen,
                     take_closest(h, t, k, best_t[p], best_i[p]);
                 }
             }
-        }
-    }
-}
-
-// RT_SHADOWS, one point light `l`: P shadow rays per lane (from hit point h toward lp, direction u, length sd).  Seen from the
-// light they share an origin, so the primary-ray 3-FMA filter applies with the per-light constants A.lfilt (scene_prep.cpp:
-// prepare_light_filters); candidates run the reference's exact general-origin test on the ORIGINAL ray (h, u), so the result is
-// bit-identical to the oracle's occluded().  Bit p of `occ` = ray p is blocked.  Contains workgroup barriers.
-// `far` marks rays whose hit point lies outside the ball the filter margins were derived for (only possible on planes): they skip
-// the filter and are tested exactly against every sphere.
-template <int P, int B, int CH>
-__device__ __forceinline__ void trace_shadow(const RenderArgs& A, float* s_buf, int tid, int l, uint32_t need, uint32_t far, const float (&hx)[P], const float (&hy)[P],
-                                             const float (&hz)[P], const float (&ux)[P], const float (&uy)[P], const float (&uz)[P],
-                                             const float (&sd)[P], uint32_t& occ)
-{
-    float* const s_x = s_buf;
-    float* const s_y = s_buf + CH;
-    float* const s_z = s_buf + 2 * CH;
-    float wx[P], wy[P], wz[P];
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        const bool on = ((need & ~far) >> p) & 1u;  // dead (and far) rays: w = 0 => f = -1, never a candidate
-        wx[p] = on ? -ux[p] : 0.0f;
-        wy[p] = on ? -uy[p] : 0.0f;
-        wz[p] = on ? -uz[p] : 0.0f;
-    }
-    occ = 0u;
-    auto exact = [&](int k) {
-        const float4 s = A.sph_r[k];
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            float t;
-            const bool h = hit_general_exact(hx[p], hy[p], hz[p], ux[p], uy[p], uz[p], s, t);
-            if (h && t > RT_SHADOW_EPS && t < sd[p] && ((need >> p) & 1u)) {
-                occ |= 1u << p;
-                wx[p] = wy[p] = wz[p] = 0.0f;  // decided: stop raising candidates
-            }
-        }
-    };
-    for (int a = 0; a < A.n_planes; ++a) {  // planes: exact test for every ray
-        const int k = A.planes[a];
-        const float4 p0 = A.sph_r[k], n = A.pln[k];
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            float t;
-            const bool h = hit_plane_exact(hx[p], hy[p], hz[p], ux[p], uy[p], uz[p], p0, n, t);
-            if (h && t > RT_SHADOW_EPS && t < sd[p] && ((need >> p) & 1u)) {
-                occ |= 1u << p;
-                wx[p] = wy[p] = wz[p] = 0.0f;
-            }
-        }
-    }
-    if (__builtin_amdgcn_ballot_w64((need & far) != 0u) != 0ull) {  // rare: hit points beyond the filter's ball, every sphere exactly
-        for (int k = 0; k < A.n; ++k) exact(k);                     // (planes and padding entries carry a NaN radius: they miss)
-    } else {
-        for (int a = A.lalways_off[l]; a < A.lalways_off[l + 1]; ++a) exact(A.lalways[a]);
-    }
-    uint32_t open = need & ~occ;
-    const float4* const filt = A.lfilt + (size_t)l * A.n_pad;
-    for (int c0 = 0; c0 < A.n_pad; c0 += CH) {
-        const int cn = min(CH, A.n_pad - c0);
-        __syncthreads();
-        for (int i = tid; i < cn; i += kWaves * 64) {
-            const float4 q = filt[c0 + i];
-            s_x[i] = q.x;
-            s_y[i] = q.y;
-            s_z[i] = q.z;
-        }
-        __syncthreads();
-        if (__builtin_amdgcn_ballot_w64(open != 0u) == 0ull) continue;  // this wave is done (barriers above still run)
-        for (int s0 = 0; s0 < cn; s0 += B) {
-            float m = -1.0f;
-            float qx[B], qy[B], qz[B];
-#pragma unroll
-            for (int g = 0; g < B; g += 4) {
-                const float4 vx = *reinterpret_cast<const float4*>(&s_x[s0 + g]);
-                const float4 vy = *reinterpret_cast<const float4*>(&s_y[s0 + g]);
-                const float4 vz = *reinterpret_cast<const float4*>(&s_z[s0 + g]);
-                qx[g] = vx.x; qx[g + 1] = vx.y; qx[g + 2] = vx.z; qx[g + 3] = vx.w;
-                qy[g] = vy.x; qy[g + 1] = vy.y; qy[g + 2] = vy.z; qy[g + 3] = vy.w;
-                qz[g] = vz.x; qz[g + 1] = vz.y; qz[g + 2] = vz.z; qz[g + 3] = vz.w;
-            }
-#pragma unroll
-            for (int b = 0; b < B; ++b)
-#pragma unroll
-                for (int p = 0; p < P; ++p)
-                    m = __builtin_fmaxf(m, __builtin_fmaf(wx[p], qx[b], __builtin_fmaf(wy[p], qy[b], __builtin_fmaf(wz[p], qz[b], -1.0f))));
-            if (__builtin_amdgcn_ballot_w64(m >= 0.0f) == 0ull) continue;
-            for (int b = 0; b < B; ++b) {
-                const float4 q = filt[c0 + s0 + b];
-                bool cand = false;
-#pragma unroll
-                for (int p = 0; p < P; ++p)
-                    cand = cand || (__builtin_fmaf(wx[p], q.x, __builtin_fmaf(wy[p], q.y, __builtin_fmaf(wz[p], q.z, -1.0f))) >= 0.0f);
-                if (__builtin_amdgcn_ballot_w64(cand) == 0ull) continue;
-                exact(c0 + s0 + b);
-            }
-            open = need & ~occ;
-            if (__builtin_amdgcn_ballot_w64(open != 0u) == 0ull) break;  // early-out: every shadow ray of this wave is blocked
         }
     }
 }
@@ -616,41 +517,150 @@ __device__ __forceinline__ void load_ray(const RenderArgs& A, uint32_t r, bool o
     }
 }
 
-// RT_SHADOWS (EXTENSION — the reference has no occlusion, light/point.rs:25-30): occlusion bits of every (record, point light)
-// pair of this iteration, semantics of the oracle's occluded().  A persistent grid pulls tiles (light l, group of 4 waves x 64 lanes
-// x P records) from the queue A.tile_ctr, light-major, so that all rays of a tile end at the same light: seen from the light they
-// share an origin and the primary loop's 3-FMA filter applies (trace_shadow) with P = 4 rays per lane — the same loop shape,
-// LDS traffic and issue rate as the primary kernel.  Result: bit (l & 31) of A.rec_occ[(l >> 5) * rec_cap + r] (zeroed by the host).
-template <int P, int B, int CH>
+// ---- RT_SHADOWS (EXTENSION — the reference has no occlusion, light/point.rs:25-30) -------------------------------------------------
+// Spatial sort of the live hit records (a counting sort on the spatial rank of the element each record sits on, scene_prep.cpp:
+// spatial_order): A.rec_perm lists the live records so that consecutive entries lie on the same or on neighbouring spheres; their
+// shadow rays toward one light then form a narrow cone, which is what the any-hit hierarchy of shadow_mask_kernel feeds on.  Also
+// drops dead records (rec_idx < 0).  Three small kernels per iteration of renderer.rs:46: histogram, exclusive scan, scatter.
+__device__ __forceinline__ int sort_key(const RenderArgs& A, uint32_t r, uint32_t count)
+{
+    if (r >= count) return -1;
+    const int idx = A.rec_idx[r];
+    return idx >= 0 ? A.rank[idx] : -1;
+}
+
+__device__ __forceinline__ uint32_t lanes_below(uint64_t mask)  // set bits of `mask` in lanes lower than this one
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// SCATTER = false: A.sort_bins[key] += records with that key (bins zeroed before).  SCATTER = true: bins hold the exclusive prefix;
+// every record takes the next free position of its bin.  One atomic per distinct key of a wave (neighbouring records share elements).
+template <bool SCATTER>
+__global__ __launch_bounds__(256) void sort_records_kernel(const RenderArgs A)
+{
+    const uint32_t count = *A.rec_count;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t base = (blockIdx.x * 256u + (threadIdx.x & ~63u)); base < count; base += gridDim.x * 256u) {
+        const uint32_t r = base + (uint32_t)lane;
+        const int key = sort_key(A, r, count);
+        uint64_t todo = __builtin_amdgcn_ballot_w64(key >= 0);
+        while (todo) {
+            const int lead = __builtin_ctzll(todo);
+            const int k0 = __builtin_amdgcn_readlane(key, lead);
+            const uint64_t same = __builtin_amdgcn_ballot_w64(key == k0);
+            uint32_t at = 0;
+            if (lane == lead) at = atomicAdd(A.sort_bins + k0, (uint32_t)__builtin_popcountll(same));
+            if (SCATTER) {
+                at = (uint32_t)__builtin_amdgcn_readlane((int)at, lead);
+                if (key == k0) A.rec_perm[at + lanes_below(same)] = r;
+            }
+            todo &= ~same;
+        }
+    }
+}
+
+// Exclusive scan of A.sort_bins[0, n) in place (one workgroup); the total = number of live records goes to A.rec_count[1].
+__global__ __launch_bounds__(256) void sort_scan_kernel(const RenderArgs A)
+{
+    __shared__ uint32_t s_part[256];
+    const uint32_t n = (uint32_t)A.n, tid = threadIdx.x;
+    const uint32_t per = (n + 255u) / 256u;
+    const uint32_t lo = min(n, tid * per), hi = min(n, lo + per);
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; ++i) sum += A.sort_bins[i];
+    s_part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (int i = 0; i < 256; ++i) {
+            const uint32_t v = s_part[i];
+            s_part[i] = run;
+            run += v;
+        }
+        A.rec_count[1] = run;
+    }
+    __syncthreads();
+    uint32_t run = s_part[tid];
+    for (uint32_t i = lo; i < hi; ++i) {
+        const uint32_t v = A.sort_bins[i];
+        A.sort_bins[i] = run;
+        run += v;
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int m = 32; m; m >>= 1) v = v + __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)  // NaN operands are ignored (fmaxf)
+{
+#pragma unroll
+    for (int m = 32; m; m >>= 1) v = __builtin_fmaxf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+__device__ __forceinline__ float wave_min(float v)
+{
+#pragma unroll
+    for (int m = 32; m; m >>= 1) v = __builtin_fminf(v, __shfl_xor(v, m, 64));
+    return v;
+}
+
+constexpr float kConeP1 = 1.0f - 3.814697265625e-06f;  // P1 = 1 - 64u of the member test (scene_prep.cpp: prepare_light_filters)
+
+// Occlusion bits of every (live record, point light) pair of this iteration, semantics of the oracle's occluded().  A persistent grid
+// whose WAVES pull tiles (light l, 64 * P consecutive entries of the spatially sorted record list) from the queue A.tile_ctr, light-major.
+// All rays of a tile end at the same light: seen from the light they share an origin and the primary loop's 3-FMA filter applies with
+// the per-light constants A.lfilt (P rays per lane, broadcast LDS reads, one wave vote per B spheres), candidates run the reference's
+// exact general-origin test on the ORIGINAL ray (h, u), so the result is bit-identical to the oracle's.
+// Any-hit hierarchy (scene_prep.cpp: prepare_light_filters): the wave bounds its rays' reversed directions by a cone (axis a,
+// half-angle theta) and their lengths by sdmax; a cluster of 16 spatially adjacent spheres is opened only if its bounding cone meets
+// the wave's and it is not farther from the light than every ray is long; its members are kept only if their own cone meets the
+// wave's.  What is kept goes to a per-wave list in LDS and is walked with the 3-FMA filter; the wave leaves as soon as all its rays
+// are blocked (the early-out).  Neither vote ever drops a sphere that the per-ray filter would pass, so the bits equal those of a walk
+// over the whole list.  Waves whose rays do not fit a 60-degree cone (light next to the surface, records on far-apart elements) open
+// every cluster.  Result: bit (l & 31) of A.rec_occ[(l >> 5) * rec_cap + r] (zeroed by launch_render).
+// `far` marks rays whose hit point lies outside the ball the filter margins were derived for (only possible on planes): a wave that
+// holds one tests every sphere exactly.  No workgroup barrier anywhere: the four waves of a workgroup are independent.
+template <int P, int B, int CAP>
 __global__ __launch_bounds__(kWaves * 64) void shadow_mask_kernel(const RenderArgs A)
 {
-    __shared__ __attribute__((aligned(16))) float s_buf[3 * CH];
-    __shared__ uint32_t s_tile;
+    static_assert(CAP % B == 0 && CAP >= 128 && B % 4 == 0, "shortlist geometry");
+    __shared__ __attribute__((aligned(16))) float s_list[kWaves][4 * CAP];  // per wave: x | y | z | element index
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
     const int lane = tid & 63;
-    const uint32_t count = *A.rec_count;
-    const uint32_t per_group = kWaves * 64 * P;
-    const uint32_t groups = (count + per_group - 1) / per_group;
+    float* const s_x = s_list[wave];
+    float* const s_y = s_x + CAP;
+    float* const s_z = s_x + 2 * CAP;
+    int* const s_i = reinterpret_cast<int*>(s_x + 3 * CAP);
+    const uint32_t live = A.rec_count[1];
+    const uint32_t per_tile = 64 * P;
+    const uint32_t groups = (live + per_tile - 1) / per_tile;
     const uint32_t n_tiles = groups * (uint32_t)A.n_lights;
+    const int n_cl = A.n_pad / 16;
     for (;;) {
-        __syncthreads();
-        if (tid == 0) s_tile = atomicAdd(A.tile_ctr, 1u);
-        __syncthreads();
-        const uint32_t t = s_tile;
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(A.tile_ctr, 1u);
+        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
         if (t >= n_tiles) break;
         const int l = (int)(t / groups);
         const float4 lp = A.lpos[l];
-        if (A.lcol[l].w != 0.0f) continue;  // ambient lights are never shadowed (uniform over the workgroup)
-        const uint32_t first = (t % groups) * per_group + (uint32_t)wave * (64 * P);
-        float hx[P], hy[P], hz[P], sx[P], sy[P], sz[P], sd[P];
+        if (A.lcol[l].w != 0.0f) continue;  // ambient lights are never shadowed
+        const uint32_t first = (t % groups) * per_tile;
+        float hx[P], hy[P], hz[P], ux[P], uy[P], uz[P], sd[P], wx[P], wy[P], wz[P];
+        uint32_t rec[P];
         uint32_t need = 0u, far = 0u;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
-            const uint32_t r = first + p * 64 + lane;
-            bool ok = r < count;
+            const uint32_t e = first + p * 64 + lane;
+            bool ok = e < live;
+            const uint32_t r = ok ? A.rec_perm[e] : 0u;
+            rec[p] = r;
             const int idx = ok ? A.rec_idx[r] : -1;
-            ok = ok && idx >= 0;  // a record whose ray has missed is dead (shade_iter_kernel)
+            ok = ok && idx >= 0;  // (the sorted list holds live records only)
             const uint32_t pix = ok ? A.rec_pix[r] : 0u;
             const float tt = ok ? A.rec_t[r] : 0.0f;
             float ox, oy, oz, dx, dy, dz;
@@ -670,18 +680,191 @@ __global__ __launch_bounds__(kWaves * 64) void shadow_mask_kernel(const RenderAr
             }
             const float vx = lp.x - hx[p], vy = lp.y - hy[p], vz = lp.z - hz[p];
             sd[p] = sqrtf(dot3_ref(vx, vy, vz, vx, vy, vz));
-            sx[p] = vx / sd[p];
-            sy[p] = vy / sd[p];
-            sz[p] = vz / sd[p];
+            ux[p] = vx / sd[p];
+            uy[p] = vy / sd[p];
+            uz[p] = vz / sd[p];
         }
-        uint32_t occ;
-        trace_shadow<P, B, CH>(A, s_buf, tid, l, need, A.n_planes ? far : 0u, hx, hy, hz, sx, sy, sz, sd, occ);
+        if (!A.n_planes) far = 0u;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const bool on = ((need & ~far) >> p) & 1u;  // dead (and far) rays: w = 0 => f = -1, never a candidate
+            wx[p] = on ? -ux[p] : 0.0f;
+            wy[p] = on ? -uy[p] : 0.0f;
+            wz[p] = on ? -uz[p] : 0.0f;
+        }
+        uint32_t occ = 0u;
+        auto exact = [&](int k) {
+            const float4 s = A.sph_r[k];
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                float tt;
+                const bool h = hit_general_exact(hx[p], hy[p], hz[p], ux[p], uy[p], uz[p], s, tt);
+                if (h && tt > RT_SHADOW_EPS && tt < sd[p] && ((need >> p) & 1u)) {
+                    occ |= 1u << p;
+                    wx[p] = wy[p] = wz[p] = 0.0f;  // decided: stop raising candidates
+                }
+            }
+        };
+        for (int a = 0; a < A.n_planes; ++a) {  // planes: exact test for every ray
+            const int k = A.planes[a];
+            const float4 p0 = A.sph_r[k], n = A.pln[k];
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                float tt;
+                const bool h = hit_plane_exact(hx[p], hy[p], hz[p], ux[p], uy[p], uz[p], p0, n, tt);
+                if (h && tt > RT_SHADOW_EPS && tt < sd[p] && ((need >> p) & 1u)) {
+                    occ |= 1u << p;
+                    wx[p] = wy[p] = wz[p] = 0.0f;
+                }
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64((need & far) != 0u) != 0ull) {  // rare: hit points beyond the filter's ball, every sphere exactly
+            for (int k = 0; k < A.n; ++k) exact(k);                     // (planes and padding entries carry a NaN radius: they miss)
+        } else {
+            for (int a = A.lalways_off[l]; a < A.lalways_off[l + 1]; ++a) exact(A.lalways[a]);
+            uint32_t open = need & ~occ;
+            if (__builtin_amdgcn_ballot_w64(open != 0u) != 0ull) {
+                // ---- the wave's cone: axis = normalised sum of the open rays' w, half-angle from the largest |a x w| ----
+                float ax = 0.0f, ay = 0.0f, az = 0.0f;
+                uint32_t fin = 0u;
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const bool f = ((open >> p) & 1u) && __builtin_isfinite(wx[p]) && __builtin_isfinite(wy[p]) && __builtin_isfinite(wz[p]);
+                    if (f) {  // (a ray with a non-finite direction misses every exact test: it needs no candidates)
+                        fin |= 1u << p;
+                        ax = ax + wx[p];
+                        ay = ay + wy[p];
+                        az = az + wz[p];
+                    }
+                }
+                ax = wave_sum(ax);
+                ay = wave_sum(ay);
+                az = wave_sum(az);
+                const float an = sqrtf(ax * ax + ay * ay + az * az);
+                ax = ax / an;
+                ay = ay / an;
+                az = az / an;
+                float cmin = INFINITY, smax = 0.0f, sdmax = 0.0f;
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    if ((fin >> p) & 1u) {
+                        const float c = ax * wx[p] + ay * wy[p] + az * wz[p];
+                        const float kx = ay * wz[p] - az * wy[p], ky = az * wx[p] - ax * wz[p], kz = ax * wy[p] - ay * wx[p];
+                        cmin = __builtin_fminf(cmin, c);
+                        smax = __builtin_fmaxf(smax, sqrtf(kx * kx + ky * ky + kz * kz));
+                    }
+                    if ((open >> p) & 1u) sdmax = __builtin_fmaxf(sdmax, sd[p]);
+                }
+                cmin = wave_min(cmin);
+                smax = wave_max(smax);
+                sdmax = wave_max(sdmax);
+                // every finite open ray lies within theta of a, theta < 60 deg, sin(theta) <= sinT, cos(theta) >= cosT (few-ulp slack)
+                const bool wide = !(an > 0.0f && an < INFINITY && cmin > 0.5f && cmin <= 2.0f);
+                const float sinT = smax * (1.0f + 1.0e-6f) + 1.0e-6f;
+                const float cosT = sqrtf(__builtin_fmaxf(0.0f, 1.0f - sinT * sinT)) * (1.0f - 1.0e-6f);
+                const float4* const clA = A.lclA + (size_t)l * n_cl;
+                const float4* const clB = A.lclB + (size_t)l * n_cl;
+                const float4* const lf = A.lfilt + (size_t)l * A.n_pad;
+                int count = 0;
+                // walk the per-wave list: the 3-FMA filter of the primary loop, B spheres per wave vote; false = every ray is blocked
+                auto walk = [&]() -> bool {
+                    const int padded = (count + B - 1) / B * B;
+                    if (count + lane < padded) {  // pad the last block with entries that never pass
+                        s_x[count + lane] = 0.0f;
+                        s_y[count + lane] = 0.0f;
+                        s_z[count + lane] = 0.0f;
+                        s_i[count + lane] = 0;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    for (int s0 = 0; s0 < padded; s0 += B) {
+                        float m = -1.0f;
+                        float qx[B], qy[B], qz[B];
+#pragma unroll
+                        for (int g = 0; g < B; g += 4) {  // wave-uniform addresses: broadcast ds_read_b128, four spheres per read
+                            const float4 vx = *reinterpret_cast<const float4*>(&s_x[s0 + g]);
+                            const float4 vy = *reinterpret_cast<const float4*>(&s_y[s0 + g]);
+                            const float4 vz = *reinterpret_cast<const float4*>(&s_z[s0 + g]);
+                            qx[g] = vx.x; qx[g + 1] = vx.y; qx[g + 2] = vx.z; qx[g + 3] = vx.w;
+                            qy[g] = vy.x; qy[g + 1] = vy.y; qy[g + 2] = vy.z; qy[g + 3] = vy.w;
+                            qz[g] = vz.x; qz[g + 1] = vz.y; qz[g + 2] = vz.z; qz[g + 3] = vz.w;
+                        }
+#pragma unroll
+                        for (int b = 0; b < B; ++b)
+#pragma unroll
+                            for (int p = 0; p < P; ++p)
+                                m = __builtin_fmaxf(m, __builtin_fmaf(wx[p], qx[b], __builtin_fmaf(wy[p], qy[b], __builtin_fmaf(wz[p], qz[b], -1.0f))));
+                        if (__builtin_amdgcn_ballot_w64(m >= 0.0f) == 0ull) continue;
+#pragma unroll
+                        for (int b = 0; b < B; ++b) {
+                            bool cand = false;
+#pragma unroll
+                            for (int p = 0; p < P; ++p)
+                                cand = cand || (__builtin_fmaf(wx[p], qx[b], __builtin_fmaf(wy[p], qy[b], __builtin_fmaf(wz[p], qz[b], -1.0f))) >= 0.0f);
+                            if (__builtin_amdgcn_ballot_w64(cand) == 0ull) continue;
+                            exact(s_i[s0 + b]);
+                        }
+                        open = need & ~occ;
+                        if (__builtin_amdgcn_ballot_w64(open != 0u) == 0ull) return false;  // early-out: every shadow ray of this wave is blocked
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    count = 0;
+                    return true;
+                };
+                bool going = true;
+                for (int cb = 0; cb < n_cl && going; cb += 64) {
+                    // ---- cluster vote: one cluster per lane ----
+                    bool pass = false;
+                    if (cb + lane < n_cl) {
+                        const float4 ca = clA[cb + lane], cs = clB[cb + lane];
+                        const float dot = __builtin_fmaf(ax, ca.x, __builtin_fmaf(ay, ca.y, az * ca.z));
+                        const float rhs = __builtin_fmaf(cosT, cs.x, -(sinT * cs.y));
+                        pass = (wide || dot >= rhs - 4.0e-6f) && !(ca.w > sdmax);
+                    }
+                    uint64_t mask = __builtin_amdgcn_ballot_w64(pass);
+                    while (mask != 0ull && going) {
+                        // ---- member vote: four open clusters at a time, 16 lanes each ----
+                        int sel = -1;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int bit = mask ? __builtin_ctzll(mask) : -1;
+                            if (i == (lane >> 4)) sel = bit;
+                            mask &= mask - 1ull;
+                        }
+                        bool keep = false;
+                        float4 q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                        int j = 0;
+                        if (sel >= 0) {
+                            j = (cb + sel) * 16 + (lane & 15);
+                            q = lf[j];
+                            const float dot = __builtin_fmaf(ax, q.x, __builtin_fmaf(ay, q.y, az * q.z));
+                            const float rhs = __builtin_fmaf(cosT, kConeP1, -(sinT * q.w));
+                            const bool entry = q.x != 0.0f || q.y != 0.0f || q.z != 0.0f;  // all zero: padding / always-list / plane
+                            keep = entry && (wide || dot >= rhs - 8.0e-6f);
+                        }
+                        const uint64_t km = __builtin_amdgcn_ballot_w64(keep);
+                        if (km == 0ull) continue;
+                        if (keep) {
+                            const int at = count + (int)lanes_below(km);
+                            s_x[at] = q.x;
+                            s_y[at] = q.y;
+                            s_z[at] = q.z;
+                            s_i[at] = A.order[j];
+                        }
+                        count += __builtin_popcountll(km);
+                        if (count > CAP - 64) going = walk();
+                    }
+                }
+                if (going && count > 0) (void)walk();
+            }
+        }
 #pragma unroll
         for (int p = 0; p < P; ++p)
-            if ((occ >> p) & 1u) atomicOr(A.rec_occ + (size_t)(l >> 5) * A.rec_cap + (first + p * 64 + lane), 1u << (l & 31));
+            if ((occ >> p) & 1u) atomicOr(A.rec_occ + (size_t)(l >> 5) * A.rec_cap + rec[p], 1u << (l & 31));
     }
-    if (tid == 0) {  // re-arm the queue (see render_kernel)
-        if (atomicAdd(A.tile_ctr + 1, 1u) == gridDim.x - 1u) {
+    if (lane == 0) {  // re-arm the queue (see render_kernel); here every WAVE does exactly one failing fetch
+        if (atomicAdd(A.tile_ctr + 1, 1u) == gridDim.x * kWaves - 1u) {
             atomicExch(A.tile_ctr, 0u);
             atomicExch(A.tile_ctr + 1, 0u);
         }
@@ -922,7 +1105,7 @@ hipError_t primary_slots(uint32_t& slots)
 hipError_t mask_slots_of_device(uint32_t& slots)
 {
     static uint32_t cache[64] = {};
-    return resident_slots(shadow_mask_kernel<kMaskP, kShadowB, kShadowChunk>, cache, slots, kMaskLdsPad);
+    return resident_slots(shadow_mask_kernel<kMaskP, kShadowB, kShadowCap>, cache, slots, kMaskLdsPad);
 }
 
 // Cut the band into the three tile sections of render_kernel and launch the persistent grid.
@@ -973,7 +1156,7 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream, PhaseEvents
     const bool shadows = (args.flags & RT_SHADOWS) != 0u && args.n_lights > 0;
     const uint64_t npix = (uint64_t)(args.y1 - args.y0) * args.w;
     if (!args.rec_count || !args.rec_pix || !args.rec_idx || !args.rec_t || args.rec_cap < npix) return hipErrorInvalidValue;
-    if ((args.depth > 1u && !args.rec_state) || (shadows && !args.rec_occ)) return hipErrorInvalidValue;
+    if ((args.depth > 1u && !args.rec_state) || (shadows && (!args.rec_occ || !args.rec_perm || !args.sort_bins))) return hipErrorInvalidValue;
     hipError_t e = clear_words(nullptr, 0, 0, 0, args.rec_count, 1, stream);
     if (e != hipSuccess) return e;
     if (phases && (e = hipEventRecord(phases->ev[0], stream)) != hipSuccess) return e;
@@ -990,12 +1173,20 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream, PhaseEvents
     for (uint32_t it = 0; it < args.depth; ++it) {  // renderer.rs:46
         a.iter = it;
         if (shadows) {
-            // only the words of this band's records (at most npix per plane), not the whole capacity of the scratch
+            // only the words of this band's records (at most npix per plane), not the whole capacity of the scratch; and the sort bins
             if ((e = clear_words(a.rec_occ, (size_t)npix, a.rec_cap, occ_words, nullptr, 0, stream)) != hipSuccess) return e;
-            const uint64_t worst_tiles = (npix + kWaves * 64 * kMaskP - 1) / (kWaves * 64 * kMaskP) * (uint64_t)args.n_lights;
+            if ((e = clear_words(a.sort_bins, (size_t)a.n + 1, 0, 1, nullptr, 0, stream)) != hipSuccess) return e;
+            // spatial sort of the live records (rec_idx of this iteration) -> rec_perm, live count -> rec_count[1]
+            const uint32_t sort_wgs = (uint32_t)(npix + 255) / 256 < 2048u ? (uint32_t)(npix + 255) / 256 : 2048u;
+            hipLaunchKernelGGL((sort_records_kernel<false>), dim3(sort_wgs), dim3(256), 0, stream, a);
+            hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(256), 0, stream, a);
+            hipLaunchKernelGGL((sort_records_kernel<true>), dim3(sort_wgs), dim3(256), 0, stream, a);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+            const uint64_t worst_tiles = (npix + 64 * kMaskP - 1) / (64 * kMaskP) * (uint64_t)args.n_lights;
             if (worst_tiles >= (1ull << 32)) return hipErrorInvalidValue;  // the tile queue counts in 32 bits
-            const uint32_t grid = worst_tiles < mask_slots ? (uint32_t)worst_tiles : mask_slots;
-            hipLaunchKernelGGL((shadow_mask_kernel<kMaskP, kShadowB, kShadowChunk>), dim3(grid), dim3(kWaves * 64), kMaskLdsPad, stream, a);
+            const uint64_t worst_wgs = (worst_tiles + kWaves - 1) / kWaves;
+            const uint32_t grid = worst_wgs < mask_slots ? (uint32_t)worst_wgs : mask_slots;
+            hipLaunchKernelGGL((shadow_mask_kernel<kMaskP, kShadowB, kShadowCap>), dim3(grid), dim3(kWaves * 64), kMaskLdsPad, stream, a);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
         const bool timed = phases && it < kPhaseIters;
@@ -1010,10 +1201,11 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream, PhaseEvents
     return hipSuccess;
 }
 
-void render_scratch_layout(const RenderArgs& args, bool& need_state, uint32_t& occ_words)
+void render_scratch_layout(const RenderArgs& args, bool& need_state, uint32_t& occ_words, uint32_t& bin_words)
 {
     need_state = args.depth > 1u;
     occ_words = ((args.flags & RT_SHADOWS) != 0u && args.n_lights > 0) ? ((uint32_t)args.n_lights + 31u) / 32u : 0u;
+    bin_words = occ_words ? ((uint32_t)args.n + 1u + 3u) / 4u * 4u : 0u;
 }
 
 const char* render_kernel_name(const RenderArgs& args)

@@ -32,7 +32,8 @@ struct rt_ctx {
     size_t scene_bytes = 0;
     const float4 *d_filt = nullptr, *d_sph = nullptr, *d_sph_r = nullptr, *d_gen = nullptr, *d_refl = nullptr, *d_lpos = nullptr, *d_lcol = nullptr;
     const int32_t* d_always = nullptr;
-    const float4* d_lfilt = nullptr;
+    const float4 *d_lfilt = nullptr, *d_lclA = nullptr, *d_lclB = nullptr;
+    const int32_t *d_order = nullptr, *d_rank = nullptr;
     const int32_t *d_lalways = nullptr, *d_lalways_off = nullptr;
     const float4* d_pln = nullptr;
     const int32_t* d_planes = nullptr;
@@ -47,6 +48,7 @@ struct rt_ctx {
     void* d_rec = nullptr;
     size_t rec_capacity = 0;   // records
     size_t rec_planes = 0;     // 4-byte planes of rec_capacity entries allocated after the 16-byte counter
+    size_t rec_bin_words = 0;  // words of sort bins allocated after the planes
     // tile-queue counters of the persistent primary kernel: a ring of slots (64 B apart), one per launch in flight
     uint32_t* d_tile_ctr = nullptr;
     hipStream_t tile_slot_stream[16] = {};  // slot i was last used by this stream (launches of one stream execute in order and can share it)
@@ -378,7 +380,12 @@ int32_t rt_scene_upload(rt_ctx* c, const rt_objects* o, const rt_lights* l)
     const size_t off_pln = off_laoff + ((nl + 1) * 4 + 15) / 16 * 16;
     const size_t npl = ps.planes.size();
     const size_t off_planes = off_pln + np * 16;
-    const size_t total = off_planes + ((npl ? npl : 1) * 4 + 15) / 16 * 16;
+    const size_t ncl = np / kShadowCluster;
+    const size_t off_clA = off_planes + ((npl ? npl : 1) * 4 + 15) / 16 * 16;
+    const size_t off_clB = off_clA + (nl ? nl : 1) * ncl * 16;
+    const size_t off_order = off_clB + (nl ? nl : 1) * ncl * 16;
+    const size_t off_rank = off_order + np * 4;
+    const size_t total = off_rank + np * 4;
     std::vector<unsigned char> host(total, 0);
     std::memcpy(host.data() + off_filt, ps.filt.data(), np * 16);
     std::memcpy(host.data() + off_sph, ps.sph.data(), np * 16);
@@ -393,6 +400,10 @@ int32_t rt_scene_upload(rt_ctx* c, const rt_objects* o, const rt_lights* l)
     std::memcpy(host.data() + off_laoff, ps.lalways_off.data(), (nl + 1) * 4);
     std::memcpy(host.data() + off_pln, ps.pln.data(), np * 16);
     if (npl) std::memcpy(host.data() + off_planes, ps.planes.data(), npl * 4);
+    if (nl) std::memcpy(host.data() + off_clA, ps.lclA.data(), nl * ncl * 16);
+    if (nl) std::memcpy(host.data() + off_clB, ps.lclB.data(), nl * ncl * 16);
+    std::memcpy(host.data() + off_order, ps.order.data(), np * 4);
+    std::memcpy(host.data() + off_rank, ps.rank.data(), np * 4);
 
     RT_HIP(c, hipDeviceSynchronize());  // no render may still read the old scene (launches may sit on caller streams too)
     if (total > c->scene_bytes) {
@@ -419,6 +430,10 @@ int32_t rt_scene_upload(rt_ctx* c, const rt_objects* o, const rt_lights* l)
     c->d_lalways_off = reinterpret_cast<const int32_t*>(base + off_laoff);
     c->d_pln = reinterpret_cast<const float4*>(base + off_pln);
     c->d_planes = reinterpret_cast<const int32_t*>(base + off_planes);
+    c->d_lclA = reinterpret_cast<const float4*>(base + off_clA);
+    c->d_lclB = reinterpret_cast<const float4*>(base + off_clB);
+    c->d_order = reinterpret_cast<const int32_t*>(base + off_order);
+    c->d_rank = reinterpret_cast<const int32_t*>(base + off_rank);
     c->n_planes = (int32_t)npl;
     std::memcpy(c->ball, ps.ball, sizeof(c->ball));
     c->n = ps.n;
@@ -505,18 +520,18 @@ static int32_t enqueue_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h
     std::memcpy(a.m, m, sizeof(a.m));
     a.w = w; a.h = h; a.y0 = y0; a.y1 = y1; a.depth = depth; a.flags = flags;
     a.n = c->n; a.n_pad = c->n_pad; a.n_always = c->n_always; a.n_lights = c->n_lights;
-    a.filt = c->d_filt; a.sph = c->d_sph; a.sph_r = c->d_sph_r; a.gen = c->d_gen; a.refl = c->d_refl; a.always = c->d_always; a.lpos = c->d_lpos; a.lcol = c->d_lcol; a.lfilt = c->d_lfilt; a.lalways = c->d_lalways; a.lalways_off = c->d_lalways_off; a.pln = c->d_pln; a.planes = c->d_planes; a.n_planes = c->n_planes; std::memcpy(a.ball, c->ball, sizeof(a.ball));
+    a.filt = c->d_filt; a.sph = c->d_sph; a.sph_r = c->d_sph_r; a.gen = c->d_gen; a.refl = c->d_refl; a.always = c->d_always; a.lpos = c->d_lpos; a.lcol = c->d_lcol; a.lfilt = c->d_lfilt; a.lclA = c->d_lclA; a.lclB = c->d_lclB; a.order = c->d_order; a.rank = c->d_rank; a.lalways = c->d_lalways; a.lalways_off = c->d_lalways_off; a.pln = c->d_pln; a.planes = c->d_planes; a.n_planes = c->n_planes; std::memcpy(a.ball, c->ball, sizeof(a.ball));
     a.out = static_cast<uint8_t*>(d_out);
     a.hit_idx = static_cast<int32_t*>(d_hit_idx);
     a.rec_count = nullptr; a.rec_pix = nullptr; a.rec_idx = nullptr; a.rec_t = nullptr;
     a.strips = a.tiles4 = a.tiles2 = a.tiles1 = a.rows4 = a.rows2 = 0;
-    a.rec_cap = 0; a.iter = 0; a.rec_state = nullptr; a.rec_occ = nullptr;
+    a.rec_cap = 0; a.iter = 0; a.rec_state = nullptr; a.rec_occ = nullptr; a.rec_perm = nullptr; a.sort_bins = nullptr;
     const bool general = render_needs_records(a);
     const size_t npix = (size_t)(y1 - y0) * w;
     bool need_state = false;
-    uint32_t occ_words = 0;
-    render_scratch_layout(a, need_state, occ_words);
-    const size_t planes = 3 + (need_state ? 9 : 0) + occ_words;
+    uint32_t occ_words = 0, bin_words = 0;
+    render_scratch_layout(a, need_state, occ_words, bin_words);
+    const size_t planes = 3 + (need_state ? 9 : 0) + occ_words + (occ_words ? 1 : 0);
 
     uint32_t slot = 0;
     char* rec_base = nullptr;
@@ -524,8 +539,8 @@ static int32_t enqueue_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h
     if (kind == ScratchKind::kStatic) {
         // [tile-queue counters (64 B) | pad to 256 | count (16 B) | planes of npix words]; everything that must start at zero is
         // cleared on `st` (the counters here; the record count and the occlusion words by launch_render)
-        if (general && kNoAllocRecOffset + 16 + npix * planes * 4 > (size_t)RT_NOALLOC_SCRATCH_BYTES)
-            return fail(c, RT_ERR_TOO_LARGE, "rt_render_rows_device_noalloc: this band needs " + std::to_string(kNoAllocRecOffset + 16 + npix * planes * 4) +
+        if (general && kNoAllocRecOffset + 16 + npix * planes * 4 + (size_t)bin_words * 4 > (size_t)RT_NOALLOC_SCRATCH_BYTES)
+            return fail(c, RT_ERR_TOO_LARGE, "rt_render_rows_device_noalloc: this band needs " + std::to_string(kNoAllocRecOffset + 16 + npix * planes * 4 + (size_t)bin_words * 4) +
                                                  " bytes of hit-record scratch, the fixed array holds " + std::to_string((size_t)RT_NOALLOC_SCRATCH_BYTES));
         a.tile_ctr = reinterpret_cast<uint32_t*>(c->noalloc_scratch);
         RT_HIP(c, clear_scratch_words(a.tile_ctr, 16, st));
@@ -537,17 +552,20 @@ static int32_t enqueue_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h
         a.tile_ctr = c->d_tile_ctr + (size_t)slot * 16;
         if (general) {
             // scratch: [count (16 B) | pix | idx | t | 9 state planes (depth > 1) | occlusion planes (RT_SHADOWS)], planes of rec_capacity words
-            if (npix > c->rec_capacity || planes > c->rec_planes) {  // grow (the previous launches that used it must be finished first)
+            if (npix > c->rec_capacity || planes > c->rec_planes || bin_words > c->rec_bin_words) {  // grow (the previous launches that used it must be finished first)
                 const size_t cap = npix > c->rec_capacity ? npix : c->rec_capacity;
                 const size_t pl = planes > c->rec_planes ? planes : c->rec_planes;
+                const size_t bw = bin_words > c->rec_bin_words ? bin_words : c->rec_bin_words;
                 RT_HIP(c, hipDeviceSynchronize());
                 if (c->d_rec) RT_HIP(c, hipFree(c->d_rec));
                 c->d_rec = nullptr;
                 c->rec_capacity = 0;
                 c->rec_planes = 0;
-                RT_HIP(c, hipMalloc(&c->d_rec, 16 + cap * pl * 4));
+                c->rec_bin_words = 0;
+                RT_HIP(c, hipMalloc(&c->d_rec, 16 + cap * pl * 4 + bw * 4));
                 c->rec_capacity = cap;
                 c->rec_planes = pl;
+                c->rec_bin_words = bw;
             }
             rec_base = static_cast<char*>(c->d_rec);
             rec_cap = c->rec_capacity;
@@ -563,7 +581,12 @@ static int32_t enqueue_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h
         a.rec_idx = reinterpret_cast<int32_t*>(rec_base + 16 + plane);
         a.rec_t = reinterpret_cast<float*>(rec_base + 16 + 2 * plane);
         if (need_state) a.rec_state = reinterpret_cast<float*>(rec_base + 16 + 3 * plane);
-        if (occ_words) a.rec_occ = reinterpret_cast<uint32_t*>(rec_base + 16 + (3 + (need_state ? 9 : 0)) * plane);
+        if (occ_words) {
+            a.rec_occ = reinterpret_cast<uint32_t*>(rec_base + 16 + (3 + (need_state ? 9 : 0)) * plane);
+            a.rec_perm = reinterpret_cast<uint32_t*>(rec_base + 16 + (3 + (need_state ? 9 : 0) + occ_words) * plane);
+            // the bins sit behind ALL planes of the layout in use (context scratch: behind its allocated planes)
+            a.sort_bins = reinterpret_cast<uint32_t*>(rec_base + 16 + (kind == ScratchKind::kStatic ? planes : c->rec_planes) * plane);
+        }
     }
     const bool time_phases = general && kind == ScratchKind::kContext && time_it;
     if (kind == ScratchKind::kContext) c->phases_valid = false;

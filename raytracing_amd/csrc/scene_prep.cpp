@@ -2,6 +2,7 @@
 // Compiled with -ffp-contract=off: `k` below must carry exactly the bits the reference computes.
 #include "scene_prep.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -63,12 +64,28 @@ void prepare_filter(int32_t n, const float* cx, const float* cy, const float* cz
  *   R^2 = r^2 + 128 u (S^2 + r^2)      and      mu = 20 u (1 + M/sqrt(k)),  k = |q'|^2 - R^2.
  * Spheres with k <= 0 (the light is inside / within the noise band of the sphere), M/sqrt(k) > 2^10 or non-finite data are
  * listed per light and tested exactly for every ray.  Candidates always go through the reference's exact test.
+ *
+ * Any-hit hierarchy on top of the filter (round 3).  The constants are stored in the SPATIAL ORDER of the spheres
+ * (out.order: Morton order of the centres), 16 consecutive entries form a CLUSTER, and the kernel bounds the reversed directions w of
+ * the 256 rays a wave holds by a cone (unit axis a, half-angle theta <= 60 deg).  A ray inside that cone can only be a candidate of
+ * sphere s (f >= 0 in the kernel's FMA arithmetic, whose error is <= 4.04 u (1 + sqrt(3) |c''|)) if, for |c''| <= 4,
+ *        w.c'' >= 1 - 33u   =>   angle(a, c'') <= theta + theta_s ,  cos(theta_s) = P1 / |c''| ,  P1 = 1 - 64u
+ *   <=>  a.c'' >= cos(theta) P1 - sin(theta) P2 ,   P2 = sqrt(|c''|^2 - P1^2)          (the MEMBER test; P2 rides in lfilt.w)
+ * and a cluster with axis e and half-angle theta_c >= angle(e, c''_s) + theta_s for all its members s can only hold a candidate if
+ *        a.e >= cos(theta) cos(theta_c) - sin(theta) sin(theta_c)                      (the CLUSTER test; lclA / lclB).
+ * Both are evaluated with a few-ulp slack in the kernel; spheres / clusters outside the argument (|c''| > 4, theta_c > 80 deg) always
+ * pass.  Independently of direction, a blocker the reference can report (RT_SHADOW_EPS < t < dist) has
+ *        |c - lp| <= dist + r + sqrt(55 u (S^2 + r^2)) ,
+ * so a cluster whose members are all farther from the light than every ray of the wave is long (dmin = min(|c - lp| - r - 6e-3 S))
+ * is skipped as well.  Neither test ever removes a sphere the per-ray filter would pass: the output is unchanged by construction.
  */
 static void prepare_light_filters(const rt_objects* o, const rt_lights* l, PreparedScene& out)
 {
     const double u = std::ldexp(1.0, -24);
-    const int32_t n = o->n, nl = l->n, np = out.n_pad;
+    const int32_t n = o->n, nl = l->n, np = out.n_pad, ncl = np / kShadowCluster;
     out.lfilt.assign((size_t)nl * np, f4{0, 0, 0, 0});
+    out.lclA.assign((size_t)nl * ncl, f4{0, 0, 0, INFINITY});  // dmin = +inf: an empty cluster never passes
+    out.lclB.assign((size_t)nl * ncl, f4{2.0f, 0, 0, 0});
     out.lalways.clear();
     out.lalways_off.assign(nl + 1, 0);
     // bounding ball of everything a ray can start from or end at: sphere surfaces, the camera (0,0,0), the lights
@@ -95,6 +112,8 @@ static void prepare_light_filters(const rt_objects* o, const rt_lights* l, Prepa
     // hit points within 0.999 Rs of C (in f32 arithmetic) are certainly inside the ball the margins below assume
     out.ball[0] = (float)C[0]; out.ball[1] = (float)C[1]; out.ball[2] = (float)C[2];
     out.ball[3] = (float)(0.998 * Rs * Rs);
+    const double P1 = 1.0 - 64.0 * u;
+    std::vector<double> th_s(kShadowCluster), ex(kShadowCluster), ey(kShadowCluster), ez(kShadowCluster);
     for (int32_t m = 0; m < nl; ++m) {
         const uint8_t kind = l->kind ? l->kind[m] : (uint8_t)RT_POINT;
         out.lalways_off[m] = (int32_t)out.lalways.size();
@@ -102,39 +121,138 @@ static void prepare_light_filters(const rt_objects* o, const rt_lights* l, Prepa
         const double lx = l->px[m], ly = l->py[m], lz = l->pz[m];
         const bool lfin = std::isfinite(lx) && std::isfinite(ly) && std::isfinite(lz);
         const double Sl = lfin ? distC(lx, ly, lz) + Rs : 0.0;  // >= every |lp - h|
-        for (int32_t i = 0; i < n; ++i) {
-            if (is_plane(i)) continue;  // lfilt stays 0 (never a candidate); planes are tested exactly through out.planes
-            bool ok = fin[i] && lfin;
-            double qx = 0, qy = 0, qz = 0, s = 1, M = 0;
-            if (ok) {
-                qx = o->cx[i] - lx; qy = o->cy[i] - ly; qz = o->cz[i] - lz;
-                const double r2 = (double)o->radius[i] * (double)o->radius[i];
-                const double S = 1.01 * std::fmax(distC(o->cx[i], o->cy[i], o->cz[i]) + Rs, Sl);  // >= every |h - c_i| and every dist
-                const double R2 = r2 + 128.0 * u * (S * S + r2);
-                const double k = qx * qx + qy * qy + qz * qz - R2;
-                M = std::fabs(qx) + std::fabs(qy) + std::fabs(qz);
-                ok = std::isfinite(k) && k > 0.0 && M >= 1e-12 && M <= 1e12;
+        for (int32_t cl = 0; cl < ncl; ++cl) {
+            int members = 0;
+            bool open_dir = false;  // some member is outside the cone argument: the cluster passes every direction test
+            double dmin = INFINITY, sx = 0, sy = 0, sz = 0;
+            for (int32_t jj = 0; jj < kShadowCluster; ++jj) {
+                const int32_t j = cl * kShadowCluster + jj;
+                const int32_t i = out.order[j];
+                if (i < 0 || is_plane(i)) continue;  // lfilt stays 0 (never a candidate); planes are tested exactly through out.planes
+                bool ok = fin[i] && lfin;
+                double qx = 0, qy = 0, qz = 0, s = 1, M = 0, dl = 0, S = 0;
                 if (ok) {
-                    s = std::sqrt(k);
-                    ok = M / s <= 1024.0;
+                    qx = o->cx[i] - lx; qy = o->cy[i] - ly; qz = o->cz[i] - lz;
+                    const double r2 = (double)o->radius[i] * (double)o->radius[i];
+                    S = 1.01 * std::fmax(distC(o->cx[i], o->cy[i], o->cz[i]) + Rs, Sl);  // >= every |h - c_i| and every dist
+                    const double R2 = r2 + 128.0 * u * (S * S + r2);
+                    dl = std::sqrt(qx * qx + qy * qy + qz * qz);
+                    const double k = qx * qx + qy * qy + qz * qz - R2;
+                    M = std::fabs(qx) + std::fabs(qy) + std::fabs(qz);
+                    ok = std::isfinite(k) && k > 0.0 && M >= 1e-12 && M <= 1e12;
+                    if (ok) {
+                        s = std::sqrt(k);
+                        ok = M / s <= 1024.0;
+                    }
                 }
-            }
-            if (ok) {
+                if (!ok) {
+                    out.lalways.push_back(i);
+                    continue;
+                }
                 const double mu = 20.0 * u * (1.0 + M / s);
                 const double g = (1.0 + mu) / s;
-                out.lfilt[(size_t)m * np + i] = f4{(float)(qx * g), (float)(qy * g), (float)(qz * g), 0.0f};
-            } else {
-                out.lalways.push_back(i);
+                f4 c2 = f4{(float)(qx * g), (float)(qy * g), (float)(qz * g), 0.0f};
+                if (c2.x == 0.0f && c2.y == 0.0f && c2.z == 0.0f) {  // (cannot happen for M/s >= 1; all-zero constants mean "no entry" to the kernel)
+                    out.lalways.push_back(i);
+                    continue;
+                }
+                // member test constants from the f32 values the kernel multiplies with
+                const double nx = c2.x, ny = c2.y, nz = c2.z, nn = std::sqrt(nx * nx + ny * ny + nz * nz);
+                double p2 = nn > P1 ? std::sqrt(nn * nn - P1 * P1) : 0.0;
+                c2.w = std::nextafter((float)p2, INFINITY);
+                if (!(nn <= 4.0)) {  // the light is close to the surface: theta_s > 75 deg, outside the cone argument
+                    c2.w = 1.0e30f;  // rhs ~ -1e30 sin(theta) with sin(theta) >= 1e-6 in the kernel: the member test always passes
+                    open_dir = true;
+                }
+                out.lfilt[(size_t)m * np + j] = c2;
+                th_s[members] = nn > P1 ? std::acos(P1 / nn) : 0.0;
+                ex[members] = nx / nn; ey[members] = ny / nn; ez[members] = nz / nn;
+                sx += ex[members]; sy += ey[members]; sz += ez[members];
+                ++members;
+                dmin = std::fmin(dmin, dl - std::fabs((double)o->radius[i]) - 6e-3 * S);
             }
+            if (!members) continue;
+            f4 A = f4{0, 0, 0, std::nextafter((float)dmin, -INFINITY)}, B = f4{-2.0f, 0, 0, 0};  // cos = -2: passes every direction test
+            const double sn = std::sqrt(sx * sx + sy * sy + sz * sz);
+            if (!open_dir && sn > 1e-6) {
+                const float ax = (float)(sx / sn), ay = (float)(sy / sn), az = (float)(sz / sn);  // the axis as the kernel sees it
+                const double an = std::sqrt((double)ax * ax + (double)ay * ay + (double)az * az);
+                double th = 0.0;
+                for (int k = 0; k < members; ++k) {
+                    double c = (ex[k] * ax + ey[k] * ay + ez[k] * az) / an;
+                    c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
+                    th = std::fmax(th, std::acos(c) + th_s[k]);
+                }
+                th += 1e-5;
+                if (th <= 80.0 * 3.14159265358979323846 / 180.0) {
+                    A.x = ax; A.y = ay; A.z = az;
+                    B.x = std::nextafter((float)std::cos(th), -INFINITY);
+                    B.y = std::nextafter((float)std::sin(th), INFINITY);
+                }
+            }
+            out.lclA[(size_t)m * ncl + cl] = A;
+            out.lclB[(size_t)m * ncl + cl] = B;
         }
     }
     out.lalways_off[nl] = (int32_t)out.lalways.size();
+}
+
+// Spatial order of the elements (Morton code of the sphere centres, 10 bits per axis over their bounding box; planes and non-finite
+// spheres last, in index order): out.order[j] = element at position j (-1 = padding), out.rank[i] = position of element i.
+// Consecutive positions are neighbours in space, so (i) 16 consecutive entries make a tight cluster for the shadow any-hit hierarchy
+// and (ii) hit records sorted by the rank of their element make waves whose shadow rays toward one light form a narrow cone.
+static void spatial_order(const rt_objects* o, PreparedScene& out)
+{
+    const int32_t n = o->n;
+    std::vector<uint64_t> key(n);
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    auto fin = [&](int32_t i) {
+        return !(o->kind && o->kind[i] == RT_PLANE) && std::isfinite(o->cx[i]) && std::isfinite(o->cy[i]) && std::isfinite(o->cz[i]);
+    };
+    for (int32_t i = 0; i < n; ++i) {
+        if (!fin(i)) continue;
+        const double v[3] = {o->cx[i], o->cy[i], o->cz[i]};
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::fmin(lo[a], v[a]);
+            hi[a] = std::fmax(hi[a], v[a]);
+        }
+    }
+    auto spread = [](uint64_t v) {  // 10 bits -> every third bit
+        uint64_t r = 0;
+        for (int b = 0; b < 10; ++b) r |= ((v >> b) & 1ull) << (3 * b);
+        return r;
+    };
+    for (int32_t i = 0; i < n; ++i) {
+        uint64_t code = 1ull << 40;  // after every finite sphere
+        if (fin(i)) {
+            const double v[3] = {o->cx[i], o->cy[i], o->cz[i]};
+            uint64_t q[3];
+            for (int a = 0; a < 3; ++a) {
+                const double ext = hi[a] - lo[a];
+                double t = ext > 0 ? (v[a] - lo[a]) / ext : 0.0;
+                t = t < 0 ? 0 : (t > 1 ? 1 : t);
+                q[a] = (uint64_t)(t * 1023.0);
+            }
+            code = spread(q[0]) | (spread(q[1]) << 1) | (spread(q[2]) << 2);
+        }
+        key[i] = (code << 22) | (uint64_t)i;  // index as tie-break: a total, deterministic order (n < 2^22 is checked by the caller)
+    }
+    std::vector<int32_t> idx(n);
+    for (int32_t i = 0; i < n; ++i) idx[i] = i;
+    std::sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
+    out.order.assign(out.n_pad, -1);
+    out.rank.assign(out.n_pad, 0);
+    for (int32_t j = 0; j < n; ++j) {
+        out.order[j] = idx[j];
+        out.rank[idx[j]] = j;
+    }
 }
 
 std::string prepare_scene(const rt_objects* o, const rt_lights* l, PreparedScene& out)
 {
     if (!o || !l) return "objects/lights is null";
     if (o->n < 0 || l->n < 0) return "negative count";
+    if (o->n >= (1 << 22)) return "more than 2^22 - 1 elements";
     if (o->n > 0 && (!o->cx || !o->cy || !o->cz || !o->radius || !o->refl_r || !o->refl_g || !o->refl_b)) return "objects: null array";
     if (l->n > 0 && (!l->cr || !l->cg || !l->cb)) return "lights: null colour array";
     for (int32_t i = 0; i < o->n; ++i) {
@@ -198,6 +316,7 @@ std::string prepare_scene(const rt_objects* o, const rt_lights* l, PreparedScene
             out.lpos[i] = f4{0, 0, 0, 0};
         out.lcol[i] = f4{l->cr[i], l->cg[i], l->cb[i], (float)kd};
     }
+    spatial_order(o, out);
     prepare_light_filters(o, l, out);
     return std::string();
 }

@@ -17,6 +17,8 @@ struct f4 {
 #define RT_PAD 16
 #endif
 constexpr int kSphereBlockPad = RT_PAD;
+constexpr int kShadowCluster = 16;  // entries per cluster of the shadow any-hit hierarchy (scene_prep.cpp: prepare_light_filters)
+static_assert(kSphereBlockPad % kShadowCluster == 0, "n_pad must be a whole number of clusters");
 
 struct PreparedScene {
     int32_t n = 0;       // elements (renderer.rs:37)
@@ -37,7 +39,10 @@ struct PreparedScene {
     std::vector<f4> lcol;        // n_lights: (cr, cg, cb, kind as float: 0 = point, 1 = ambient)
     // RT_SHADOWS: per light the shadow rays share the end point lp, so seen from the light they are "primary rays" and the
     // 3-FMA filter applies with sphere centres relative to lp and an inflated radius (scene_prep.cpp: prepare_light_filters)
-    std::vector<f4> lfilt;             // n_lights * n_pad: (c''x, c''y, c''z, 0); all zero for ambient lights
+    std::vector<int32_t> order;        // n_pad: element at spatial position j (Morton order of the sphere centres; planes last), -1 = padding
+    std::vector<int32_t> rank;         // n_pad: spatial position of element i (the sort key of the hit records)
+    std::vector<f4> lfilt;             // n_lights * n_pad, in SPATIAL order: (c''x, c''y, c''z, P2 of the member test); all zero = no entry
+    std::vector<f4> lclA, lclB;        // n_lights * n_pad / 16: per cluster of 16 consecutive entries (axis x, y, z, dmin), (cos, sin of the half-angle, 0, 0)
     std::vector<int32_t> lalways;      // per light, indices of spheres its filter cannot cover (concatenated)
     std::vector<int32_t> lalways_off;  // n_lights + 1 offsets into lalways
 };
