@@ -25,6 +25,7 @@ struct RenderArgs {
     const float4* lclA;         // n_lights * n_pad / 16: per cluster of 16 entries (cone axis x, y, z, dmin)
     const float4* lclB;         // n_lights * n_pad / 16: (cos, sin of the cluster's half-angle, 0, 0)
     const int32_t* order;       // n_pad: element at spatial position j, -1 = padding
+    const float4* sph_o;        // n_pad: sph_r in spatial order (position j holds element order[j]; padding: NaN radius)
     const int32_t* rank;        // n_pad: spatial position of element i (sort key of the hit records)
     const int32_t* lalways;     // per-light always-test lists, concatenated
     const int32_t* lalways_off; // n_lights + 1
@@ -44,6 +45,7 @@ struct RenderArgs {
     float* rec_state;     // depth > 1: 9 planes of rec_cap floats (origin, direction, colour of the bounce ray); else null
     uint32_t* rec_occ;    // RT_SHADOWS: ceil(n_lights / 32) planes of rec_cap words, occlusion bit per (record, light); else null
     uint32_t* rec_perm;   // RT_SHADOWS: rec_cap words, the live records of this iteration in spatial order (rec_count[1] entries); else null
+    float* rec_hit;       // RT_SHADOWS: 3 planes of rec_cap floats, the hit points of those records in the same (sorted) order; else null
     uint32_t* sort_bins;  // RT_SHADOWS: n + 1 words, histogram / running offsets of the record sort; else null
     // tile queue of the persistent primary kernel: tile_ctr[0] = next tile, tile_ctr[1] = workgroups that have left (library-owned,
     // zero between launches); the rest is filled in by launch_render
@@ -85,7 +87,7 @@ hipError_t clear_scratch_words(uint32_t* q, uint32_t nq, hipStream_t stream);
 bool render_needs_records(const RenderArgs& args);
 
 // Which optional scratch these args need beside count/pix/idx/t: rec_state (9 float planes), rec_occ (occ_words planes) and, with
-// occ_words > 0, one more plane (rec_perm) plus bin_words words of sort bins.
+// occ_words > 0, four more planes (rec_perm, rec_hit x 3) plus bin_words words of sort bins.
 void render_scratch_layout(const RenderArgs& args, bool& need_state, uint32_t& occ_words, uint32_t& bin_words);
 
 // Name of the kernel variant launch_render picks for these args (for profiles / bench output).

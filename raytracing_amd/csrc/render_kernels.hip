@@ -544,6 +544,7 @@ __global__ __launch_bounds__(256) void sort_records_kernel(const RenderArgs A)
     for (uint32_t base = (blockIdx.x * 256u + (threadIdx.x & ~63u)); base < count; base += gridDim.x * 256u) {
         const uint32_t r = base + (uint32_t)lane;
         const int key = sort_key(A, r, count);
+        uint32_t dst = 0;
         uint64_t todo = __builtin_amdgcn_ballot_w64(key >= 0);
         while (todo) {
             const int lead = __builtin_ctzll(todo);
@@ -553,9 +554,24 @@ __global__ __launch_bounds__(256) void sort_records_kernel(const RenderArgs A)
             if (lane == lead) at = atomicAdd(A.sort_bins + k0, (uint32_t)__builtin_popcountll(same));
             if (SCATTER) {
                 at = (uint32_t)__builtin_amdgcn_readlane((int)at, lead);
-                if (key == k0) A.rec_perm[at + lanes_below(same)] = r;
+                if (key == k0) dst = at + lanes_below(same);
             }
             todo &= ~same;
+        }
+        if (SCATTER) {
+            // the hit point of the record (renderer.rs:57), once per iteration instead of once per light, stored in SORTED order so that
+            // shadow_mask_kernel reads it with unit stride
+            const bool ok = key >= 0;
+            float ox, oy, oz, dx, dy, dz;
+            load_ray(A, r, ok, ok ? A.rec_pix[r] : 0u, ox, oy, oz, dx, dy, dz);
+            const float tt = ok ? A.rec_t[r] : 0.0f;
+            if (ok) {
+                const size_t c = A.rec_cap;
+                A.rec_perm[dst] = r;
+                A.rec_hit[dst] = ox + tt * dx;
+                A.rec_hit[c + dst] = oy + tt * dy;
+                A.rec_hit[2 * c + dst] = oz + tt * dz;
+            }
         }
     }
 }
@@ -611,257 +627,314 @@ __device__ __forceinline__ float wave_min(float v)
 constexpr float kConeP1 = 1.0f - 3.814697265625e-06f;  // P1 = 1 - 64u of the member test (scene_prep.cpp: prepare_light_filters)
 
 // Occlusion bits of every (live record, point light) pair of this iteration, semantics of the oracle's occluded().  A persistent grid
-// whose WAVES pull tiles (light l, 64 * P consecutive entries of the spatially sorted record list) from the queue A.tile_ctr, light-major.
-// All rays of a tile end at the same light: seen from the light they share an origin and the primary loop's 3-FMA filter applies with
-// the per-light constants A.lfilt (P rays per lane, broadcast LDS reads, one wave vote per B spheres), candidates run the reference's
-// exact general-origin test on the ORIGINAL ray (h, u), so the result is bit-identical to the oracle's.
+// whose WAVES pull tiles (64 * P consecutive entries of the spatially sorted record list, one word = 32 lights of the occlusion plane)
+// from the queue A.tile_ctr.  The wave computes its hit points once and then takes the lights one by one.
+// All rays toward one light end at the same point: seen from the light they share an origin and the primary loop's 3-FMA filter
+// applies with the per-light constants A.lfilt (P rays per lane, broadcast LDS reads, one wave vote per B spheres); candidates run the
+// reference's exact general-origin test on the ORIGINAL ray (h, u), so the result is bit-identical to the oracle's.
 // Any-hit hierarchy (scene_prep.cpp: prepare_light_filters): the wave bounds its rays' reversed directions by a cone (axis a,
 // half-angle theta) and their lengths by sdmax; a cluster of 16 spatially adjacent spheres is opened only if its bounding cone meets
 // the wave's and it is not farther from the light than every ray is long; its members are kept only if their own cone meets the
-// wave's.  What is kept goes to a per-wave list in LDS and is walked with the 3-FMA filter; the wave leaves as soon as all its rays
-// are blocked (the early-out).  Neither vote ever drops a sphere that the per-ray filter would pass, so the bits equal those of a walk
-// over the whole list.  Waves whose rays do not fit a 60-degree cone (light next to the surface, records on far-apart elements) open
-// every cluster.  Result: bit (l & 31) of A.rec_occ[(l >> 5) * rec_cap + r] (zeroed by launch_render).
+// wave's.  What is kept goes to a per-wave list in LDS and is walked with the 3-FMA filter; the wave leaves a light as soon as all
+// its rays are blocked (the early-out).  Neither vote ever drops a sphere that the per-ray filter would pass, so the bits equal those
+// of a walk over the whole list.  Waves whose rays do not fit a 60-degree cone (light next to the surface, records on far-apart
+// elements) open every cluster.  Result: bit (l & 31) of A.rec_occ[(l >> 5) * rec_cap + r] (a tile covers LC lights of one word; the
+// words are zeroed by launch_render unless a tile owns whole words, LC = 32).
 // `far` marks rays whose hit point lies outside the ball the filter margins were derived for (only possible on planes): a wave that
 // holds one tests every sphere exactly.  No workgroup barrier anywhere: the four waves of a workgroup are independent.
-template <int P, int B, int CAP>
+template <int P, int B, int CAP, int LC, int TB, int MG>
 __global__ __launch_bounds__(kWaves * 64) void shadow_mask_kernel(const RenderArgs A)
 {
-    static_assert(CAP % B == 0 && CAP >= 128 && B % 4 == 0, "shortlist geometry");
-    __shared__ __attribute__((aligned(16))) float s_list[kWaves][4 * CAP];  // per wave: x | y | z | element index
+    static_assert(CAP % B == 0 && CAP >= 128 && B % 4 == 0 && LC >= 1 && 32 % LC == 0, "shortlist geometry");
+    __shared__ __attribute__((aligned(16))) float s_list[kWaves][7 * CAP];  // per wave: filter x | y | z, then the sphere (cx, cy, cz, r) per entry
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
     const int lane = tid & 63;
     float* const s_x = s_list[wave];
     float* const s_y = s_x + CAP;
     float* const s_z = s_x + 2 * CAP;
-    int* const s_i = reinterpret_cast<int*>(s_x + 3 * CAP);
+    float4* const s_s = reinterpret_cast<float4*>(s_x + 3 * CAP);
+    __shared__ int s_open[kWaves][256];  // per wave: the clusters the current vote opened
+    int* const s_cl = s_open[wave];
     const uint32_t live = A.rec_count[1];
     const uint32_t per_tile = 64 * P;
     const uint32_t groups = (live + per_tile - 1) / per_tile;
-    const uint32_t n_tiles = groups * (uint32_t)A.n_lights;
+    const uint32_t chunks = ((uint32_t)A.n_lights + LC - 1) / LC;
+    const uint32_t n_tiles = groups * chunks;
     const int n_cl = A.n_pad / 16;
+    uint32_t t_next = 0, t_stop = 0;
     for (;;) {
-        uint32_t t = 0;
-        if (lane == 0) t = atomicAdd(A.tile_ctr, 1u);
-        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
-        if (t >= n_tiles) break;
-        const int l = (int)(t / groups);
-        const float4 lp = A.lpos[l];
-        if (A.lcol[l].w != 0.0f) continue;  // ambient lights are never shadowed
+        if (t_next == t_stop) {  // fetch TB tiles at a time: returning atomics on ONE address complete at ~80 M/s chip-wide, a rate the small
+            uint32_t t0 = 0;     // tiles of this kernel would otherwise be bound by (tiles of either size took 12-14 ns each)
+            if (lane == 0) t0 = atomicAdd(A.tile_ctr, (uint32_t)TB);
+            t_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)t0);
+            t_stop = t_next + TB;
+            if (t_next >= n_tiles) break;
+        }
+        const uint32_t t = t_next++;
+        if (t >= n_tiles) continue;
+        const uint32_t chunk = t / groups;  // chunk-major: waves that run together work on the same lights (their constants stay in the caches)
+        const uint32_t word = chunk * LC / 32u;
         const uint32_t first = (t % groups) * per_tile;
-        float hx[P], hy[P], hz[P], ux[P], uy[P], uz[P], sd[P], wx[P], wy[P], wz[P];
-        uint32_t rec[P];
-        uint32_t need = 0u, far = 0u;
+        float hx[P], hy[P], hz[P];
+        uint32_t rec[P], occw[P];
+        uint32_t okm = 0u, far = 0u;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             const uint32_t e = first + p * 64 + lane;
-            bool ok = e < live;
-            const uint32_t r = ok ? A.rec_perm[e] : 0u;
-            rec[p] = r;
-            const int idx = ok ? A.rec_idx[r] : -1;
-            ok = ok && idx >= 0;  // (the sorted list holds live records only)
-            const uint32_t pix = ok ? A.rec_pix[r] : 0u;
-            const float tt = ok ? A.rec_t[r] : 0.0f;
-            float ox, oy, oz, dx, dy, dz;
-            load_ray(A, r, ok, pix, ox, oy, oz, dx, dy, dz);
-            hx[p] = ox + tt * dx;  // renderer.rs:57
-            hy[p] = oy + tt * dy;
-            hz[p] = oz + tt * dz;
+            const bool ok = e < live;  // (the sorted list holds live records only)
+            const size_t i = ok ? e : 0u;
+            rec[p] = A.rec_perm[i];
+            occw[p] = 0u;
+            if (ok) okm |= 1u << p;
+            hx[p] = A.rec_hit[i];  // renderer.rs:57, computed by the scatter kernel
+            hy[p] = A.rec_hit[(size_t)A.rec_cap + i];
+            hz[p] = A.rec_hit[2 * (size_t)A.rec_cap + i];
             {  // inside the ball the per-light filter margins assume?  (NaN compares false => far)
                 const float bx = hx[p] - A.ball[0], by = hy[p] - A.ball[1], bz = hz[p] - A.ball[2];
                 if (!(bx * bx + by * by + bz * bz <= A.ball[3])) far |= 1u << p;
             }
-            {  // light/point.rs:25-30: a light whose contribution is cut off casts no shadow ray
-                const float vx = hx[p] - lp.x, vy = hy[p] - lp.y, vz = hz[p] - lp.z;
-                const float dist = sqrtf(dot3_ref(vx, vy, vz, vx, vy, vz));
-                const float in = lp.w / (dist * dist);
-                if (ok && !(in <= 1.1920929e-7f)) need |= 1u << p;
-            }
-            const float vx = lp.x - hx[p], vy = lp.y - hy[p], vz = lp.z - hz[p];
-            sd[p] = sqrtf(dot3_ref(vx, vy, vz, vx, vy, vz));
-            ux[p] = vx / sd[p];
-            uy[p] = vy / sd[p];
-            uz[p] = vz / sd[p];
         }
         if (!A.n_planes) far = 0u;
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            const bool on = ((need & ~far) >> p) & 1u;  // dead (and far) rays: w = 0 => f = -1, never a candidate
-            wx[p] = on ? -ux[p] : 0.0f;
-            wy[p] = on ? -uy[p] : 0.0f;
-            wz[p] = on ? -uz[p] : 0.0f;
-        }
-        uint32_t occ = 0u;
-        auto exact = [&](int k) {
-            const float4 s = A.sph_r[k];
+        const int l_end = min(A.n_lights, (int)(chunk * LC + LC));
+        for (int l = (int)(chunk * LC); l < l_end; ++l) {
+            const float4 lp = A.lpos[l];
+            if (A.lcol[l].w != 0.0f) continue;  // ambient lights are never shadowed
+            float ux[P], uy[P], uz[P], sd[P], wx[P], wy[P], wz[P];
+            uint32_t need = 0u;
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                float tt;
-                const bool h = hit_general_exact(hx[p], hy[p], hz[p], ux[p], uy[p], uz[p], s, tt);
-                if (h && tt > RT_SHADOW_EPS && tt < sd[p] && ((need >> p) & 1u)) {
-                    occ |= 1u << p;
-                    wx[p] = wy[p] = wz[p] = 0.0f;  // decided: stop raising candidates
+                {  // light/point.rs:25-30: a light whose contribution is cut off casts no shadow ray
+                    const float vx = hx[p] - lp.x, vy = hy[p] - lp.y, vz = hz[p] - lp.z;
+                    const float dist = sqrtf(dot3_ref(vx, vy, vz, vx, vy, vz));
+                    const float in = lp.w / (dist * dist);
+                    if (((okm >> p) & 1u) && !(in <= 1.1920929e-7f)) need |= 1u << p;
                 }
+                const float vx = lp.x - hx[p], vy = lp.y - hy[p], vz = lp.z - hz[p];
+                sd[p] = sqrtf(dot3_ref(vx, vy, vz, vx, vy, vz));
+                ux[p] = vx / sd[p];
+                uy[p] = vy / sd[p];
+                uz[p] = vz / sd[p];
+                const bool on = ((need & ~far) >> p) & 1u;  // dead (and far) rays: w = 0 => f = -1, never a candidate
+                wx[p] = on ? -ux[p] : 0.0f;
+                wy[p] = on ? -uy[p] : 0.0f;
+                wz[p] = on ? -uz[p] : 0.0f;
             }
-        };
-        for (int a = 0; a < A.n_planes; ++a) {  // planes: exact test for every ray
-            const int k = A.planes[a];
-            const float4 p0 = A.sph_r[k], n = A.pln[k];
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                float tt;
-                const bool h = hit_plane_exact(hx[p], hy[p], hz[p], ux[p], uy[p], uz[p], p0, n, tt);
-                if (h && tt > RT_SHADOW_EPS && tt < sd[p] && ((need >> p) & 1u)) {
-                    occ |= 1u << p;
-                    wx[p] = wy[p] = wz[p] = 0.0f;
-                }
-            }
-        }
-        if (__builtin_amdgcn_ballot_w64((need & far) != 0u) != 0ull) {  // rare: hit points beyond the filter's ball, every sphere exactly
-            for (int k = 0; k < A.n; ++k) exact(k);                     // (planes and padding entries carry a NaN radius: they miss)
-        } else {
-            for (int a = A.lalways_off[l]; a < A.lalways_off[l + 1]; ++a) exact(A.lalways[a]);
-            uint32_t open = need & ~occ;
-            if (__builtin_amdgcn_ballot_w64(open != 0u) != 0ull) {
-                // ---- the wave's cone: axis = normalised sum of the open rays' w, half-angle from the largest |a x w| ----
-                float ax = 0.0f, ay = 0.0f, az = 0.0f;
-                uint32_t fin = 0u;
+            uint32_t occ = 0u;
+            // the reference's test of sphere s for the ray slots named in `slots` (wave-uniform: a slot none of whose 64 rays is a candidate is skipped)
+            auto exact = [&](const float4 s, uint32_t slots = ~0u) {
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
-                    const bool f = ((open >> p) & 1u) && __builtin_isfinite(wx[p]) && __builtin_isfinite(wy[p]) && __builtin_isfinite(wz[p]);
-                    if (f) {  // (a ray with a non-finite direction misses every exact test: it needs no candidates)
-                        fin |= 1u << p;
-                        ax = ax + wx[p];
-                        ay = ay + wy[p];
-                        az = az + wz[p];
+                    if (!((slots >> p) & 1u)) continue;
+                    float tt;
+                    const bool h = hit_general_exact(hx[p], hy[p], hz[p], ux[p], uy[p], uz[p], s, tt);
+                    if (h && tt > RT_SHADOW_EPS && tt < sd[p] && ((need >> p) & 1u)) {
+                        occ |= 1u << p;
+                        wx[p] = wy[p] = wz[p] = 0.0f;  // decided: stop raising candidates
                     }
                 }
-                ax = wave_sum(ax);
-                ay = wave_sum(ay);
-                az = wave_sum(az);
-                const float an = sqrtf(ax * ax + ay * ay + az * az);
-                ax = ax / an;
-                ay = ay / an;
-                az = az / an;
-                float cmin = INFINITY, smax = 0.0f, sdmax = 0.0f;
+            };
+            for (int a = 0; a < A.n_planes; ++a) {  // planes: exact test for every ray
+                const int k = A.planes[a];
+                const float4 p0 = A.sph_r[k], n = A.pln[k];
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
-                    if ((fin >> p) & 1u) {
-                        const float c = ax * wx[p] + ay * wy[p] + az * wz[p];
-                        const float kx = ay * wz[p] - az * wy[p], ky = az * wx[p] - ax * wz[p], kz = ax * wy[p] - ay * wx[p];
-                        cmin = __builtin_fminf(cmin, c);
-                        smax = __builtin_fmaxf(smax, sqrtf(kx * kx + ky * ky + kz * kz));
+                    float tt;
+                    const bool h = hit_plane_exact(hx[p], hy[p], hz[p], ux[p], uy[p], uz[p], p0, n, tt);
+                    if (h && tt > RT_SHADOW_EPS && tt < sd[p] && ((need >> p) & 1u)) {
+                        occ |= 1u << p;
+                        wx[p] = wy[p] = wz[p] = 0.0f;
                     }
-                    if ((open >> p) & 1u) sdmax = __builtin_fmaxf(sdmax, sd[p]);
                 }
-                cmin = wave_min(cmin);
-                smax = wave_max(smax);
-                sdmax = wave_max(sdmax);
-                // every finite open ray lies within theta of a, theta < 60 deg, sin(theta) <= sinT, cos(theta) >= cosT (few-ulp slack)
-                const bool wide = !(an > 0.0f && an < INFINITY && cmin > 0.5f && cmin <= 2.0f);
-                const float sinT = smax * (1.0f + 1.0e-6f) + 1.0e-6f;
-                const float cosT = sqrtf(__builtin_fmaxf(0.0f, 1.0f - sinT * sinT)) * (1.0f - 1.0e-6f);
-                const float4* const clA = A.lclA + (size_t)l * n_cl;
-                const float4* const clB = A.lclB + (size_t)l * n_cl;
-                const float4* const lf = A.lfilt + (size_t)l * A.n_pad;
-                int count = 0;
-                // walk the per-wave list: the 3-FMA filter of the primary loop, B spheres per wave vote; false = every ray is blocked
-                auto walk = [&]() -> bool {
-                    const int padded = (count + B - 1) / B * B;
-                    if (count + lane < padded) {  // pad the last block with entries that never pass
-                        s_x[count + lane] = 0.0f;
-                        s_y[count + lane] = 0.0f;
-                        s_z[count + lane] = 0.0f;
-                        s_i[count + lane] = 0;
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    for (int s0 = 0; s0 < padded; s0 += B) {
-                        float m = -1.0f;
-                        float qx[B], qy[B], qz[B];
+            }
+            if (__builtin_amdgcn_ballot_w64((need & far) != 0u) != 0ull) {  // rare: hit points beyond the filter's ball, every sphere exactly
+                for (int k = 0; k < A.n; ++k) exact(A.sph_r[k]);            // (planes and padding entries carry a NaN radius: they miss)
+            } else {
+                for (int a = A.lalways_off[l]; a < A.lalways_off[l + 1]; ++a) exact(A.sph_r[A.lalways[a]]);
+                uint32_t open = need & ~occ;
+                if (__builtin_amdgcn_ballot_w64(open != 0u) != 0ull) {
+                    // ---- the wave's cone: axis = normalised sum of the open rays' w, half-angle from the largest |a x w| ----
+                    float ax = 0.0f, ay = 0.0f, az = 0.0f;
+                    uint32_t fin = 0u;
 #pragma unroll
-                        for (int g = 0; g < B; g += 4) {  // wave-uniform addresses: broadcast ds_read_b128, four spheres per read
-                            const float4 vx = *reinterpret_cast<const float4*>(&s_x[s0 + g]);
-                            const float4 vy = *reinterpret_cast<const float4*>(&s_y[s0 + g]);
-                            const float4 vz = *reinterpret_cast<const float4*>(&s_z[s0 + g]);
-                            qx[g] = vx.x; qx[g + 1] = vx.y; qx[g + 2] = vx.z; qx[g + 3] = vx.w;
-                            qy[g] = vy.x; qy[g + 1] = vy.y; qy[g + 2] = vy.z; qy[g + 3] = vy.w;
-                            qz[g] = vz.x; qz[g + 1] = vz.y; qz[g + 2] = vz.z; qz[g + 3] = vz.w;
+                    for (int p = 0; p < P; ++p) {
+                        const bool f = ((open >> p) & 1u) && __builtin_isfinite(wx[p]) && __builtin_isfinite(wy[p]) && __builtin_isfinite(wz[p]);
+                        if (f) {  // (a ray with a non-finite direction misses every exact test: it needs no candidates)
+                            fin |= 1u << p;
+                            ax = ax + wx[p];
+                            ay = ay + wy[p];
+                            az = az + wz[p];
                         }
+                    }
+                    ax = wave_sum(ax);
+                    ay = wave_sum(ay);
+                    az = wave_sum(az);
+                    const float an = sqrtf(ax * ax + ay * ay + az * az);
+                    ax = ax / an;
+                    ay = ay / an;
+                    az = az / an;
+                    float cmin = INFINITY, smax = 0.0f, sdmax = 0.0f;
 #pragma unroll
-                        for (int b = 0; b < B; ++b)
-#pragma unroll
-                            for (int p = 0; p < P; ++p)
-                                m = __builtin_fmaxf(m, __builtin_fmaf(wx[p], qx[b], __builtin_fmaf(wy[p], qy[b], __builtin_fmaf(wz[p], qz[b], -1.0f))));
-                        if (__builtin_amdgcn_ballot_w64(m >= 0.0f) == 0ull) continue;
-#pragma unroll
-                        for (int b = 0; b < B; ++b) {
-                            bool cand = false;
-#pragma unroll
-                            for (int p = 0; p < P; ++p)
-                                cand = cand || (__builtin_fmaf(wx[p], qx[b], __builtin_fmaf(wy[p], qy[b], __builtin_fmaf(wz[p], qz[b], -1.0f))) >= 0.0f);
-                            if (__builtin_amdgcn_ballot_w64(cand) == 0ull) continue;
-                            exact(s_i[s0 + b]);
+                    for (int p = 0; p < P; ++p) {
+                        if ((fin >> p) & 1u) {
+                            const float c = ax * wx[p] + ay * wy[p] + az * wz[p];
+                            const float kx = ay * wz[p] - az * wy[p], ky = az * wx[p] - ax * wz[p], kz = ax * wy[p] - ay * wx[p];
+                            cmin = __builtin_fminf(cmin, c);
+                            smax = __builtin_fmaxf(smax, sqrtf(kx * kx + ky * ky + kz * kz));
                         }
-                        open = need & ~occ;
-                        if (__builtin_amdgcn_ballot_w64(open != 0u) == 0ull) return false;  // early-out: every shadow ray of this wave is blocked
+                        if ((open >> p) & 1u) sdmax = __builtin_fmaxf(sdmax, sd[p]);
                     }
-                    __builtin_amdgcn_wave_barrier();
-                    count = 0;
-                    return true;
-                };
-                bool going = true;
-                for (int cb = 0; cb < n_cl && going; cb += 64) {
-                    // ---- cluster vote: one cluster per lane ----
-                    bool pass = false;
-                    if (cb + lane < n_cl) {
-                        const float4 ca = clA[cb + lane], cs = clB[cb + lane];
-                        const float dot = __builtin_fmaf(ax, ca.x, __builtin_fmaf(ay, ca.y, az * ca.z));
-                        const float rhs = __builtin_fmaf(cosT, cs.x, -(sinT * cs.y));
-                        pass = (wide || dot >= rhs - 4.0e-6f) && !(ca.w > sdmax);
+                    cmin = wave_min(cmin);
+                    smax = wave_max(smax);
+                    sdmax = wave_max(sdmax);
+                    // every finite open ray lies within theta of a, theta < 60 deg, sin(theta) <= sinT, cos(theta) >= cosT (few-ulp slack)
+                    const bool wide = !(an > 0.0f && an < INFINITY && cmin > 0.5f && cmin <= 2.0f);
+#ifdef RT_MASK_STATS
+                    if (lane == 0) {
+                        atomicAdd(A.tile_ctr + 2, 1u);
+                        if (wide) atomicAdd(A.tile_ctr + 3, 1u);
+                        atomicAdd(A.tile_ctr + 8, (uint32_t)(smax * 1000.0f));
                     }
-                    uint64_t mask = __builtin_amdgcn_ballot_w64(pass);
-                    while (mask != 0ull && going) {
-                        // ---- member vote: four open clusters at a time, 16 lanes each ----
-                        int sel = -1;
+#endif
+                    const float sinT = smax * (1.0f + 1.0e-6f) + 1.0e-6f;
+                    const float cosT = sqrtf(__builtin_fmaxf(0.0f, 1.0f - sinT * sinT)) * (1.0f - 1.0e-6f);
+                    const float4* const clA = A.lclA + (size_t)l * n_cl;
+                    const float4* const clB = A.lclB + (size_t)l * n_cl;
+                    const float4* const lf = A.lfilt + (size_t)l * A.n_pad;
+                    int count = 0;
+                    // walk the per-wave list: the 3-FMA filter of the primary loop, B spheres per wave vote; false = every ray is blocked
+                    auto walk = [&]() -> bool {
+                        const int padded = (count + B - 1) / B * B;
+                        if (count + lane < padded) {  // pad the last block with entries that never pass
+                            s_x[count + lane] = 0.0f;
+                            s_y[count + lane] = 0.0f;
+                            s_z[count + lane] = 0.0f;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        for (int s0 = 0; s0 < padded; s0 += B) {
+                            float m = -1.0f;
+                            float qx[B], qy[B], qz[B];
+#pragma unroll
+                            for (int g = 0; g < B; g += 4) {  // wave-uniform addresses: broadcast ds_read_b128, four spheres per read
+                                const float4 vx = *reinterpret_cast<const float4*>(&s_x[s0 + g]);
+                                const float4 vy = *reinterpret_cast<const float4*>(&s_y[s0 + g]);
+                                const float4 vz = *reinterpret_cast<const float4*>(&s_z[s0 + g]);
+                                qx[g] = vx.x; qx[g + 1] = vx.y; qx[g + 2] = vx.z; qx[g + 3] = vx.w;
+                                qy[g] = vy.x; qy[g + 1] = vy.y; qy[g + 2] = vy.z; qy[g + 3] = vy.w;
+                                qz[g] = vz.x; qz[g + 1] = vz.y; qz[g + 2] = vz.z; qz[g + 3] = vz.w;
+                            }
+#pragma unroll
+                            for (int b = 0; b < B; ++b)
+#pragma unroll
+                                for (int p = 0; p < P; ++p)
+                                    m = __builtin_fmaxf(m, __builtin_fmaf(wx[p], qx[b], __builtin_fmaf(wy[p], qy[b], __builtin_fmaf(wz[p], qz[b], -1.0f))));
+                            if (__builtin_amdgcn_ballot_w64(m >= 0.0f) == 0ull) continue;
+#pragma unroll
+                            for (int b = 0; b < B; ++b) {
+                                uint32_t slots = 0u;
+#pragma unroll
+                                for (int p = 0; p < P; ++p) {
+                                    const bool cand = __builtin_fmaf(wx[p], qx[b], __builtin_fmaf(wy[p], qy[b], __builtin_fmaf(wz[p], qz[b], -1.0f))) >= 0.0f;
+                                    if (__builtin_amdgcn_ballot_w64(cand) != 0ull) slots |= 1u << p;
+                                }
+                                if (slots == 0u) continue;
+#ifdef RT_MASK_STATS
+                                if (lane == 0) atomicAdd(A.tile_ctr + 6, (uint32_t)__builtin_popcount(slots));
+#endif
+                                exact(s_s[s0 + b], slots);
+                            }
+                            open = need & ~occ;
+                            if (__builtin_amdgcn_ballot_w64(open != 0u) == 0ull) {
+#ifdef RT_MASK_STATS
+                                if (lane == 0) atomicAdd(A.tile_ctr + 7, 1u);
+#endif
+                                return false;  // early-out: every shadow ray of this wave is blocked
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        count = 0;
+                        return true;
+                    };
+                    bool going = true;
+#ifdef RT_MASK_SKIP_WIDE  // DEV timing experiment only (wrong image): what do the wide waves cost?
+                    if (wide) going = false;
+#endif
+                    for (int cb = 0; cb < n_cl && going; cb += 256) {
+                        // ---- cluster vote: four clusters per lane, their loads in flight together; open clusters -> s_cl ----
+                        float4 ca[4], cs[4];
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
-                            const int bit = mask ? __builtin_ctzll(mask) : -1;
-                            if (i == (lane >> 4)) sel = bit;
-                            mask &= mask - 1ull;
+                            const int c = cb + 64 * i + lane;
+                            ca[i] = c < n_cl ? clA[c] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                            cs[i] = c < n_cl ? clB[c] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                         }
-                        bool keep = false;
-                        float4 q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                        int j = 0;
-                        if (sel >= 0) {
-                            j = (cb + sel) * 16 + (lane & 15);
-                            q = lf[j];
-                            const float dot = __builtin_fmaf(ax, q.x, __builtin_fmaf(ay, q.y, az * q.z));
-                            const float rhs = __builtin_fmaf(cosT, kConeP1, -(sinT * q.w));
-                            const bool entry = q.x != 0.0f || q.y != 0.0f || q.z != 0.0f;  // all zero: padding / always-list / plane
-                            keep = entry && (wide || dot >= rhs - 8.0e-6f);
+                        int n_open = 0;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int c = cb + 64 * i + lane;
+                            const float dot = __builtin_fmaf(ax, ca[i].x, __builtin_fmaf(ay, ca[i].y, az * ca[i].z));
+                            const float rhs = __builtin_fmaf(cosT, cs[i].x, -(sinT * cs[i].y));
+                            const bool pass = c < n_cl && (wide || dot >= rhs - 4.0e-6f) && !(ca[i].w > sdmax);
+                            const uint64_t mask = __builtin_amdgcn_ballot_w64(pass);
+                            if (pass) s_cl[n_open + (int)lanes_below(mask)] = c;
+                            n_open += __builtin_popcountll(mask);
                         }
-                        const uint64_t km = __builtin_amdgcn_ballot_w64(keep);
-                        if (km == 0ull) continue;
-                        if (keep) {
-                            const int at = count + (int)lanes_below(km);
-                            s_x[at] = q.x;
-                            s_y[at] = q.y;
-                            s_z[at] = q.z;
-                            s_i[at] = A.order[j];
+#ifdef RT_MASK_STATS
+                        if (lane == 0) atomicAdd(A.tile_ctr + 4, (uint32_t)n_open);
+#endif
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        // ---- member vote: 4 * MG open clusters at a time (16 lanes per cluster; MG loads per lane in flight together) ----
+                        for (int base = 0; base < n_open && going; base += 4 * MG) {
+                            float4 q[MG], sp[MG];
+#pragma unroll
+                            for (int i = 0; i < MG; ++i) {
+                                const int ci = base + 4 * i + (lane >> 4);
+                                const int j = (ci < n_open ? s_cl[ci] : 0) * 16 + (lane & 15);
+                                q[i] = ci < n_open ? lf[j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                                sp[i] = A.sph_o[j];  // the sphere itself, same spatial order: candidates are tested out of LDS, no dependent load
+                            }
+#pragma unroll
+                            for (int i = 0; i < MG; ++i) {
+                                const float dot = __builtin_fmaf(ax, q[i].x, __builtin_fmaf(ay, q[i].y, az * q[i].z));
+                                const float rhs = __builtin_fmaf(cosT, kConeP1, -(sinT * q[i].w));
+                                const bool entry = q[i].x != 0.0f || q[i].y != 0.0f || q[i].z != 0.0f;  // all zero: padding / always-list / plane / no cluster
+                                const bool keep = entry && (wide || dot >= rhs - 8.0e-6f);
+                                const uint64_t km = __builtin_amdgcn_ballot_w64(keep);
+                                if (km == 0ull || !going) continue;
+                                if (keep) {
+                                    const int at = count + (int)lanes_below(km);
+                                    s_x[at] = q[i].x;
+                                    s_y[at] = q[i].y;
+                                    s_z[at] = q[i].z;
+                                    s_s[at] = sp[i];
+                                }
+                                count += __builtin_popcountll(km);
+#ifdef RT_MASK_STATS
+                                if (lane == 0) atomicAdd(A.tile_ctr + 5, (uint32_t)__builtin_popcountll(km));
+#endif
+                                if (count > CAP - 64) going = walk();
+                            }
                         }
-                        count += __builtin_popcountll(km);
-                        if (count > CAP - 64) going = walk();
+                        __builtin_amdgcn_wave_barrier();
                     }
+                    if (going && count > 0) (void)walk();
                 }
-                if (going && count > 0) (void)walk();
             }
+#pragma unroll
+            for (int p = 0; p < P; ++p) occw[p] |= ((occ >> p) & 1u) << (l & 31);
         }
 #pragma unroll
-        for (int p = 0; p < P; ++p)
-            if ((occ >> p) & 1u) atomicOr(A.rec_occ + (size_t)(l >> 5) * A.rec_cap + rec[p], 1u << (l & 31));
+        for (int p = 0; p < P; ++p) {
+            if (LC == 32) {  // the tile owns the whole word
+                if ((okm >> p) & 1u) A.rec_occ[(size_t)word * A.rec_cap + rec[p]] = occw[p];
+            } else if (occw[p]) {
+                atomicOr(A.rec_occ + (size_t)word * A.rec_cap + rec[p], occw[p]);
+            }
+        }
     }
     if (lane == 0) {  // re-arm the queue (see render_kernel); here every WAVE does exactly one failing fetch
         if (atomicAdd(A.tile_ctr + 1, 1u) == gridDim.x * kWaves - 1u) {
@@ -1036,6 +1109,18 @@ constexpr int kShadeP = RT_SHADE_P;  // records per lane in shade_iter_kernel
 #define RT_MASK_P 4
 #endif
 constexpr int kMaskP = RT_MASK_P;   // shadow rays per lane in shadow_mask_kernel
+#ifndef RT_MASK_LC
+#define RT_MASK_LC 1
+#endif
+constexpr int kMaskLC = RT_MASK_LC; // lights per tile of shadow_mask_kernel
+#ifndef RT_MASK_TB
+#define RT_MASK_TB 4
+#endif
+constexpr int kMaskTB = RT_MASK_TB; // tiles a wave takes from the queue per atomic
+#ifndef RT_MASK_MG
+#define RT_MASK_MG 1
+#endif
+constexpr int kMaskMG = RT_MASK_MG; // member loads per lane in flight together in shadow_mask_kernel (4 * MG open clusters per step)
 
 }  // namespace
 
@@ -1105,7 +1190,7 @@ hipError_t primary_slots(uint32_t& slots)
 hipError_t mask_slots_of_device(uint32_t& slots)
 {
     static uint32_t cache[64] = {};
-    return resident_slots(shadow_mask_kernel<kMaskP, kShadowB, kShadowCap>, cache, slots, kMaskLdsPad);
+    return resident_slots(shadow_mask_kernel<kMaskP, kShadowB, kShadowCap, kMaskLC, kMaskTB, kMaskMG>, cache, slots, kMaskLdsPad);
 }
 
 // Cut the band into the three tile sections of render_kernel and launch the persistent grid.
@@ -1156,7 +1241,7 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream, PhaseEvents
     const bool shadows = (args.flags & RT_SHADOWS) != 0u && args.n_lights > 0;
     const uint64_t npix = (uint64_t)(args.y1 - args.y0) * args.w;
     if (!args.rec_count || !args.rec_pix || !args.rec_idx || !args.rec_t || args.rec_cap < npix) return hipErrorInvalidValue;
-    if ((args.depth > 1u && !args.rec_state) || (shadows && (!args.rec_occ || !args.rec_perm || !args.sort_bins))) return hipErrorInvalidValue;
+    if ((args.depth > 1u && !args.rec_state) || (shadows && (!args.rec_occ || !args.rec_perm || !args.rec_hit || !args.sort_bins))) return hipErrorInvalidValue;
     hipError_t e = clear_words(nullptr, 0, 0, 0, args.rec_count, 1, stream);
     if (e != hipSuccess) return e;
     if (phases && (e = hipEventRecord(phases->ev[0], stream)) != hipSuccess) return e;
@@ -1174,7 +1259,7 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream, PhaseEvents
         a.iter = it;
         if (shadows) {
             // only the words of this band's records (at most npix per plane), not the whole capacity of the scratch; and the sort bins
-            if ((e = clear_words(a.rec_occ, (size_t)npix, a.rec_cap, occ_words, nullptr, 0, stream)) != hipSuccess) return e;
+            if (kMaskLC != 32 && (e = clear_words(a.rec_occ, (size_t)npix, a.rec_cap, occ_words, nullptr, 0, stream)) != hipSuccess) return e;
             if ((e = clear_words(a.sort_bins, (size_t)a.n + 1, 0, 1, nullptr, 0, stream)) != hipSuccess) return e;
             // spatial sort of the live records (rec_idx of this iteration) -> rec_perm, live count -> rec_count[1]
             const uint32_t sort_wgs = (uint32_t)(npix + 255) / 256 < 2048u ? (uint32_t)(npix + 255) / 256 : 2048u;
@@ -1182,11 +1267,11 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream, PhaseEvents
             hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(256), 0, stream, a);
             hipLaunchKernelGGL((sort_records_kernel<true>), dim3(sort_wgs), dim3(256), 0, stream, a);
             if ((e = hipGetLastError()) != hipSuccess) return e;
-            const uint64_t worst_tiles = (npix + 64 * kMaskP - 1) / (64 * kMaskP) * (uint64_t)args.n_lights;
+            const uint64_t worst_tiles = (npix + 64 * kMaskP - 1) / (64 * kMaskP) * (uint64_t)(((uint32_t)args.n_lights + kMaskLC - 1) / kMaskLC);
             if (worst_tiles >= (1ull << 32)) return hipErrorInvalidValue;  // the tile queue counts in 32 bits
             const uint64_t worst_wgs = (worst_tiles + kWaves - 1) / kWaves;
             const uint32_t grid = worst_wgs < mask_slots ? (uint32_t)worst_wgs : mask_slots;
-            hipLaunchKernelGGL((shadow_mask_kernel<kMaskP, kShadowB, kShadowCap>), dim3(grid), dim3(kWaves * 64), kMaskLdsPad, stream, a);
+            hipLaunchKernelGGL((shadow_mask_kernel<kMaskP, kShadowB, kShadowCap, kMaskLC, kMaskTB, kMaskMG>), dim3(grid), dim3(kWaves * 64), kMaskLdsPad, stream, a);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
         const bool timed = phases && it < kPhaseIters;

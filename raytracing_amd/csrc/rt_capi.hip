@@ -32,7 +32,7 @@ struct rt_ctx {
     size_t scene_bytes = 0;
     const float4 *d_filt = nullptr, *d_sph = nullptr, *d_sph_r = nullptr, *d_gen = nullptr, *d_refl = nullptr, *d_lpos = nullptr, *d_lcol = nullptr;
     const int32_t* d_always = nullptr;
-    const float4 *d_lfilt = nullptr, *d_lclA = nullptr, *d_lclB = nullptr;
+    const float4 *d_lfilt = nullptr, *d_lclA = nullptr, *d_lclB = nullptr, *d_sph_o = nullptr;
     const int32_t *d_order = nullptr, *d_rank = nullptr;
     const int32_t *d_lalways = nullptr, *d_lalways_off = nullptr;
     const float4* d_pln = nullptr;
@@ -193,6 +193,18 @@ int32_t rt_debug_prepare_spheres(const rt_objects* o, float* filt, uint8_t* cls)
     prepare_filter(o->n, o->cx, o->cy, o->cz, o->radius, reinterpret_cast<f4*>(filt), cls, nullptr);
     return RT_OK;
 }
+
+#ifdef RT_MASK_STATS
+// DEV build only: the 16 words of tile-queue slot 0 (words 2.. hold the shadow kernel's statistics), then zero words 2..15
+int32_t rt_debug_read_stats(rt_ctx* c, uint32_t out[16])
+{
+    if (!c || !out) return RT_ERR_INVALID;
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(out, c->d_tile_ctr, 64, hipMemcpyDeviceToHost);
+    (void)hipMemset(c->d_tile_ctr + 2, 0, 56);
+    return RT_OK;
+}
+#endif
 
 int32_t rt_debug_tile_plan(uint32_t w, uint32_t rows, uint32_t slots, uint32_t plan[6])
 {
@@ -385,7 +397,8 @@ int32_t rt_scene_upload(rt_ctx* c, const rt_objects* o, const rt_lights* l)
     const size_t off_clB = off_clA + (nl ? nl : 1) * ncl * 16;
     const size_t off_order = off_clB + (nl ? nl : 1) * ncl * 16;
     const size_t off_rank = off_order + np * 4;
-    const size_t total = off_rank + np * 4;
+    const size_t off_sph_o = off_rank + np * 4;
+    const size_t total = off_sph_o + np * 16;
     std::vector<unsigned char> host(total, 0);
     std::memcpy(host.data() + off_filt, ps.filt.data(), np * 16);
     std::memcpy(host.data() + off_sph, ps.sph.data(), np * 16);
@@ -404,6 +417,7 @@ int32_t rt_scene_upload(rt_ctx* c, const rt_objects* o, const rt_lights* l)
     if (nl) std::memcpy(host.data() + off_clB, ps.lclB.data(), nl * ncl * 16);
     std::memcpy(host.data() + off_order, ps.order.data(), np * 4);
     std::memcpy(host.data() + off_rank, ps.rank.data(), np * 4);
+    std::memcpy(host.data() + off_sph_o, ps.sph_o.data(), np * 16);
 
     RT_HIP(c, hipDeviceSynchronize());  // no render may still read the old scene (launches may sit on caller streams too)
     if (total > c->scene_bytes) {
@@ -434,6 +448,7 @@ int32_t rt_scene_upload(rt_ctx* c, const rt_objects* o, const rt_lights* l)
     c->d_lclB = reinterpret_cast<const float4*>(base + off_clB);
     c->d_order = reinterpret_cast<const int32_t*>(base + off_order);
     c->d_rank = reinterpret_cast<const int32_t*>(base + off_rank);
+    c->d_sph_o = reinterpret_cast<const float4*>(base + off_sph_o);
     c->n_planes = (int32_t)npl;
     std::memcpy(c->ball, ps.ball, sizeof(c->ball));
     c->n = ps.n;
@@ -520,18 +535,18 @@ static int32_t enqueue_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h
     std::memcpy(a.m, m, sizeof(a.m));
     a.w = w; a.h = h; a.y0 = y0; a.y1 = y1; a.depth = depth; a.flags = flags;
     a.n = c->n; a.n_pad = c->n_pad; a.n_always = c->n_always; a.n_lights = c->n_lights;
-    a.filt = c->d_filt; a.sph = c->d_sph; a.sph_r = c->d_sph_r; a.gen = c->d_gen; a.refl = c->d_refl; a.always = c->d_always; a.lpos = c->d_lpos; a.lcol = c->d_lcol; a.lfilt = c->d_lfilt; a.lclA = c->d_lclA; a.lclB = c->d_lclB; a.order = c->d_order; a.rank = c->d_rank; a.lalways = c->d_lalways; a.lalways_off = c->d_lalways_off; a.pln = c->d_pln; a.planes = c->d_planes; a.n_planes = c->n_planes; std::memcpy(a.ball, c->ball, sizeof(a.ball));
+    a.filt = c->d_filt; a.sph = c->d_sph; a.sph_r = c->d_sph_r; a.gen = c->d_gen; a.refl = c->d_refl; a.always = c->d_always; a.lpos = c->d_lpos; a.lcol = c->d_lcol; a.lfilt = c->d_lfilt; a.lclA = c->d_lclA; a.lclB = c->d_lclB; a.order = c->d_order; a.sph_o = c->d_sph_o; a.rank = c->d_rank; a.lalways = c->d_lalways; a.lalways_off = c->d_lalways_off; a.pln = c->d_pln; a.planes = c->d_planes; a.n_planes = c->n_planes; std::memcpy(a.ball, c->ball, sizeof(a.ball));
     a.out = static_cast<uint8_t*>(d_out);
     a.hit_idx = static_cast<int32_t*>(d_hit_idx);
     a.rec_count = nullptr; a.rec_pix = nullptr; a.rec_idx = nullptr; a.rec_t = nullptr;
     a.strips = a.tiles4 = a.tiles2 = a.tiles1 = a.rows4 = a.rows2 = 0;
-    a.rec_cap = 0; a.iter = 0; a.rec_state = nullptr; a.rec_occ = nullptr; a.rec_perm = nullptr; a.sort_bins = nullptr;
+    a.rec_cap = 0; a.iter = 0; a.rec_state = nullptr; a.rec_occ = nullptr; a.rec_perm = nullptr; a.rec_hit = nullptr; a.sort_bins = nullptr;
     const bool general = render_needs_records(a);
     const size_t npix = (size_t)(y1 - y0) * w;
     bool need_state = false;
     uint32_t occ_words = 0, bin_words = 0;
     render_scratch_layout(a, need_state, occ_words, bin_words);
-    const size_t planes = 3 + (need_state ? 9 : 0) + occ_words + (occ_words ? 1 : 0);
+    const size_t planes = 3 + (need_state ? 9 : 0) + occ_words + (occ_words ? 4 : 0);
 
     uint32_t slot = 0;
     char* rec_base = nullptr;
@@ -584,6 +599,7 @@ static int32_t enqueue_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h
         if (occ_words) {
             a.rec_occ = reinterpret_cast<uint32_t*>(rec_base + 16 + (3 + (need_state ? 9 : 0)) * plane);
             a.rec_perm = reinterpret_cast<uint32_t*>(rec_base + 16 + (3 + (need_state ? 9 : 0) + occ_words) * plane);
+            a.rec_hit = reinterpret_cast<float*>(rec_base + 16 + (3 + (need_state ? 9 : 0) + occ_words + 1) * plane);
             // the bins sit behind ALL planes of the layout in use (context scratch: behind its allocated planes)
             a.sort_bins = reinterpret_cast<uint32_t*>(rec_base + 16 + (kind == ScratchKind::kStatic ? planes : c->rec_planes) * plane);
         }

@@ -317,6 +317,9 @@ std::string prepare_scene(const rt_objects* o, const rt_lights* l, PreparedScene
         out.lcol[i] = f4{l->cr[i], l->cg[i], l->cb[i], (float)kd};
     }
     spatial_order(o, out);
+    out.sph_o.assign(out.n_pad, f4{0, 0, 0, NAN});
+    for (int32_t j = 0; j < out.n_pad; ++j)
+        if (out.order[j] >= 0) out.sph_o[j] = out.sph_r[out.order[j]];
     prepare_light_filters(o, l, out);
     return std::string();
 }

@@ -40,6 +40,7 @@ struct PreparedScene {
     // RT_SHADOWS: per light the shadow rays share the end point lp, so seen from the light they are "primary rays" and the
     // 3-FMA filter applies with sphere centres relative to lp and an inflated radius (scene_prep.cpp: prepare_light_filters)
     std::vector<int32_t> order;        // n_pad: element at spatial position j (Morton order of the sphere centres; planes last), -1 = padding
+    std::vector<f4> sph_o;             // n_pad: sph_r in spatial order (the exact-test operands of shadow candidates)
     std::vector<int32_t> rank;         // n_pad: spatial position of element i (the sort key of the hit records)
     std::vector<f4> lfilt;             // n_lights * n_pad, in SPATIAL order: (c''x, c''y, c''z, P2 of the member test); all zero = no entry
     std::vector<f4> lclA, lclB;        // n_lights * n_pad / 16: per cluster of 16 consecutive entries (axis x, y, z, dmin), (cos, sin of the half-angle, 0, 0)
