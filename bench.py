@@ -24,7 +24,7 @@ if ROOT not in sys.path:
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 FLOPS_PER_TEST = 6             # the hot loop executes three v_fma_f32 per (pixel, sphere) pair (render_kernels.h)
 FLOPS_PER_SHADOW_TEST = 6      # shadow_mask_kernel: the same 3-FMA filter per (shadow ray, sphere) with per-light constants
-FLOPS_PER_BOUNCE_TEST = 16     # trace_general: 3 sub + (2 FMA + 1 mul) + 3 FMA + 1 FMA per (bounce ray, sphere) = 10 VALU ops
+FLOPS_PER_BOUNCE_TEST = 15     # trace_general: 7 FMA + 1 add per (bounce ray, sphere) = 8 VALU ops (round 2: 10 ops, 16 flops)
 
 
 def main():
@@ -257,15 +257,16 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(events[k])
-    for s_ in range(slots):  # the closing event of every stream's last step
-        events[args.steps + s_].record(streams[(args.steps + s_) % slots])
+    for s_ in range(slots):  # the closing event of every stream's last step: "step steps + s_" would run on stream (frame_no + s_) % slots
+        events[args.steps + s_].record(streams[(frame_no[0] + s_) % slots])
     t_issued = time.perf_counter()
     fence()
     t1 = time.perf_counter()
     print("rank %d: host issued %d steps in %.3f ms (%.1f us per step), all done after %.3f ms" %
           (rank, args.steps, (t_issued - t0) * 1e3, (t_issued - t0) * 1e6 / max(1, args.steps), (t1 - t0) * 1e3), file=sys.stderr)
     elapsed = t1 - t0
-    # step k runs on stream k % slots; the next event on that stream is the one of step k + slots (or the closing one)
+    # timed step k runs on stream (F0 + k) % slots (F0 = frames issued before the timed region); the next event on that stream is the one
+    # of step k + slots (or the closing one)
     kern_ms = sum(events[k].elapsed_time(events[k + slots]) for k in range(args.steps)) / max(1, args.steps)
 
     # General path: per-kernel durations of a launch come from the library's own HIP events between its kernels (rt_last_phase_ms):

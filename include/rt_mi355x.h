@@ -8,8 +8,9 @@
  *
  * Conventions
  *   - every function returns RT_OK (0) or a negative RT_ERR_*; no exception crosses the boundary;
- *   - a rt_ctx is bound to ONE device (one process per GPU; multi-GPU = one ctx per rank, row bands, see
- *     rt_render_rows*) and is NOT thread-safe (mirrors `&mut self` of Renderer::render, renderer.rs:32);
+ *   - a context from rt_ctx_create is bound to ONE device (one process per GPU: one ctx per rank, row bands, see rt_render_rows*); a
+ *     context from rt_ctx_create_multi spans a list of devices of this process and splits every call into row bands itself.  Neither
+ *     is thread-safe (mirrors `&mut self` of Renderer::render, renderer.rs:32);
  *   - arrays passed in are borrowed for the duration of the call only;
  *   - every entry point makes ctx's device current while it runs and restores the caller's current device before it returns;
  *   - there is no CPU fallback: without a usable gfx950 device rt_ctx_create fails with RT_ERR_NO_DEVICE.
@@ -143,6 +144,11 @@ int32_t rt_render_rows(rt_ctx* ctx, const float m[16], uint32_t w, uint32_t h, u
  * tile-queue counters out of 16 slots, recycled as launches complete — any number of streams over the life of a ctx; with more than
  * 16 streams busy AT ONCE the extra launches wait (stream-level) for a slot.  Launches with depth > 1 or RT_SHADOWS share the ctx's
  * hit-record scratch: the library orders each one after the previous one (stream-level wait on an event), whatever their streams.
+ * A stream must be idle when the caller destroys it: the library remembers streams by handle (their tile-queue slot), and a new stream
+ * that re-uses the handle of one destroyed with work in flight would share that work's counters.
+ * Multi-device contexts: the root device's bands run on `stream`, every other device's on a stream the context owns; a call on another
+ * `stream` than the previous call's is ordered after that stream's work (the root's staging is shared between frames), so the
+ * previous stream must still exist at that moment.
  */
 int32_t rt_render_rows_device(rt_ctx* ctx, const float m[16], uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t depth, uint32_t flags,
                               void* d_out, void* d_hit_idx, void* stream);
@@ -153,8 +159,9 @@ int32_t rt_render_rows_device(rt_ctx* ctx, const float m[16], uint32_t w, uint32
  * rt_render_rows_device, but the call allocates and frees nothing: the kernels' scratch (tile-queue counters; for depth > 1 or
  * RT_SHADOWS the dense hit records) lives in a fixed array of RT_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds from
  * load to process exit.  Primary-only launches (depth == 1, no RT_SHADOWS) fit at any size; a general launch needs
- * 272 + 4 * P * (y1 - y0) * w bytes, P = 3 + (depth > 1 ? 9 : 0) + (RT_SHADOWS ? ceil(n_lights / 32) : 0), and is refused with
- * RT_ERR_TOO_LARGE beyond (e.g. shadows with <= 32 lights: 2.09 Mpixel per call; depth 2: 699 kpixel; cut larger frames into row bands).
+ * 272 + 4 * P * (y1 - y0) * w bytes, P = 3 + (depth > 1 ? 9 : 0) + (RT_SHADOWS ? ceil(n_lights / 32) + 4 : 0), plus 4 * (n + 4) bytes of
+ * sort bins with RT_SHADOWS (n = elements of the scene), and is refused with RT_ERR_TOO_LARGE beyond (e.g. shadows with <= 32 lights:
+ * 1.04 Mpixel per call; depth 2: 699 kpixel; cut larger frames into row bands).
  * All calls on one GPU — of any context, of any thread — share that GPU's array: calls that overlap in time on one GPU race; order
  * them (one stream, or events).  Does not update rt_last_kernel_ms.  Capturable: everything the call enqueues is a kernel launch (the
  * scratch is cleared by a kernel too), so a HIP graph captured around it replays to the same bytes (tests/test_zz_no_alloc.py).
@@ -192,6 +199,16 @@ int32_t rt_last_phase_ms(rt_ctx* ctx, float ms[3]);
  * cls[n] = 1 if the sphere is filterable, 0 if it is always tested exactly.  See DESIGN.md "primary-ray filter".
  */
 int32_t rt_debug_prepare_spheres(const rt_objects* objects, float* filt, uint8_t* cls);
+
+/*
+ * Host-only introspection of the RT_SHADOWS any-hit hierarchy rt_scene_upload builds for point light `light` (no device needed; used
+ * by the CPU tests; no reference counterpart, like RT_SHADOWS itself).  With n_pad = n rounded up to 16 (at least 16):
+ * order[n_pad] = element at spatial position j (-1 = padding); lfilt[4*n_pad] = per position (c''x, c''y, c''z, P2): the shadow filter
+ * w.c'' - 1 >= 0 and the constant of the member cone test; cl_a / cl_b[4*n_pad/16] = per cluster of 16 positions (cone axis, dmin) and
+ * (cos, sin of its half-angle); always[<= n] / *n_always = the elements this light tests exactly for every ray.  See DESIGN.md 3.3.
+ */
+int32_t rt_debug_prepare_shadow_cull(const rt_objects* objects, const rt_lights* lights, int32_t light, int32_t* order, float* lfilt,
+                                     float* cl_a, float* cl_b, int32_t* always, int32_t* n_always);
 
 /*
  * Host-only introspection of how a band of `rows` rows x `w` columns is cut into the tile queue of the primary kernel when the

@@ -33,6 +33,7 @@ EXPORTS = (
     "rt_version", "rt_ctx_create", "rt_ctx_destroy", "rt_last_error", "rt_camera_transform", "rt_camera_default",
     "rt_scene_upload", "rt_render", "rt_render_rows", "rt_render_rows_device", "rt_last_kernel_ms",
     "rt_debug_prepare_spheres", "rt_host_alloc", "rt_host_free", "rt_debug_tile_plan", "rt_render_rows_device_noalloc", "rt_last_phase_ms", "rt_ctx_create_multi", "rt_transform_apply",
+    "rt_debug_prepare_shadow_cull",
 )
 
 _f32p = C.POINTER(C.c_float)
@@ -94,6 +95,8 @@ def load() -> C.CDLL:
     lib.rt_last_kernel_ms.argtypes = [vp, _f32p]
     lib.rt_last_phase_ms.argtypes = [vp, _f32p]
     lib.rt_debug_prepare_spheres.argtypes = [C.POINTER(RtObjects), _f32p, _u8p]
+    _i32p = C.POINTER(C.c_int32)
+    lib.rt_debug_prepare_shadow_cull.argtypes = [C.POINTER(RtObjects), C.POINTER(RtLights), C.c_int32, _i32p, _f32p, _f32p, _f32p, _i32p, _i32p]
     for name in EXPORTS:
         if name not in ("rt_version", "rt_last_error"):
             getattr(lib, name).restype = C.c_int32
@@ -198,6 +201,24 @@ def debug_prepare_spheres(objs: FlatObjects):
     if rc != RT_OK:
         raise RtError(rc, "rt_debug_prepare_spheres")
     return filt, cls
+
+
+def debug_prepare_shadow_cull(objs: FlatObjects, lights: FlatLights, light: int) -> dict:
+    """Host-only: the any-hit hierarchy of RT_SHADOWS for one point light (rt_debug_prepare_shadow_cull)."""
+    n_pad = max(16, (objs.n + 15) // 16 * 16)
+    order = np.zeros(n_pad, dtype=np.int32)
+    lfilt = np.zeros((n_pad, 4), dtype=np.float32)
+    cl_a = np.zeros((n_pad // 16, 4), dtype=np.float32)
+    cl_b = np.zeros((n_pad // 16, 4), dtype=np.float32)
+    always = np.zeros(max(1, objs.n), dtype=np.int32)
+    n_always = C.c_int32()
+    o, l = objs.c_struct(), lights.c_struct()
+    i32p = C.POINTER(C.c_int32)
+    rc = load().rt_debug_prepare_shadow_cull(C.byref(o), C.byref(l), light, order.ctypes.data_as(i32p), lfilt.ctypes.data_as(_f32p),
+                                             cl_a.ctypes.data_as(_f32p), cl_b.ctypes.data_as(_f32p), always.ctypes.data_as(i32p), C.byref(n_always))
+    if rc != RT_OK:
+        raise RtError(rc, "rt_debug_prepare_shadow_cull")
+    return {"order": order, "lfilt": lfilt, "cl_a": cl_a, "cl_b": cl_b, "always": always[: n_always.value]}
 
 
 class Context:

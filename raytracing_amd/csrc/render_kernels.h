@@ -80,9 +80,6 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream, PhaseEvents
 // persistent kernels).  Called once per context.
 hipError_t prime_launch_caches();
 
-// Zero up to 16 scratch words at q on `stream` with a kernel (graph-capture safe, see clear_words_kernel).
-hipError_t clear_scratch_words(uint32_t* q, uint32_t nq, hipStream_t stream);
-
 // True if launch_render needs the rec_* scratch buffers for these args (depth > 1 or RT_SHADOWS).
 bool render_needs_records(const RenderArgs& args);
 

@@ -154,46 +154,63 @@ __device__ __forceinline__ void shade(const RenderArgs& A, bool active, int k, f
     cb = cb * rf.z;
 }
 
-// ---- general-origin rays (bounces, shadow rays) --------------------------------------------------------------------------
-// Conservative filter for a ray (o, u) against sphere (c, r), the reference's own formula (sphere.rs:27-29) evaluated
-// with FMAs and a relative safety margin eta = 2^-17 folded into the operands:
-//     q = o - c ;  a' = u'.q  (u' = u (1 + 2^-16)) ;  W = |q|^2 - rho  (rho = r^2 (1+eta)/(1-eta), host) ;  g = a'^2 - W
-// A reference hit needs delta = fl(alpha^2) - fl(|q|^2 - r^2) >= 0; fused and unfused evaluation of that expression differ by
-// < 48 u (|q|^2 + r^2) (u = 2^-24), so g >= 0 whenever the reference's delta >= 0.  10 FMA-class ops per (ray, sphere).
+// ---- general-origin rays (bounces) ---------------------------------------------------------------------------------------------
+// Conservative filter for a ray (o, u) against sphere (c, r): the reference's own formula (sphere.rs:27-29)
+//     q = o - c ;  delta = (u.q)^2 - (|q|^2 - r^2)
+// expanded around the scene centre B (A.ball) so that no per-pair subtraction is left:  o' = o - B, c' = c - B,
+//     a' = u'.o' - u'.c'                    = fma(-u'x, c'x, fma(-u'y, c'y, fma(-u'z, c'z, A0)))       A0 = u'.o'   (per ray)
+//     W  = |o'|^2 - 2 o'.c' + |c'|^2 - rho  = fma(-2o'x, c'x, fma(-2o'y, c'y, fma(-2o'z, c'z, O2 + Kc)))
+//     g  = fma(a', a', -W)                                                   7 FMAs + 1 add per (ray, sphere), 15 flops
+// Margins: u' = u (1 + 2^-16) and rho = r^2 (1+eta)/(1-eta), eta = 2^-17, cover the difference between fused and unfused evaluation of
+// the reference's expression (< 48 u (|q|^2 + r^2), u = 2^-24) as before; the expansion adds cancellation error <= 52 u (|o'|^2 + |c'|^2)
+// (roundings of o', c', O2, Kc, the sum and the seven FMAs), covered per ray by O2 = |o'|^2 (1 - 64u) and per sphere by
+// Kc = |c'|^2 (1 - 64u) - rho, rounded down (scene_prep.cpp).  So g >= 0 whenever the reference's delta >= 0; candidates run the exact test.
 constexpr float kGenDirScale = 1.0f + 1.52587890625e-05f;  // 1 + 2^-16
+constexpr float kGenO2Scale = 1.0f - 3.814697265625e-06f;  // 1 - 64u
 #ifndef RT_GEN_BLOCK
 #define RT_GEN_BLOCK 4
 #endif
 constexpr int kGenBlock = RT_GEN_BLOCK;                    // spheres per wave vote in the general loops
 
 template <int P>
-__device__ __forceinline__ float general_filter(int p, const float (&ox)[P], const float (&oy)[P], const float (&oz)[P], const float (&fx)[P],
-                                                const float (&fy)[P], const float (&fz)[P], float cx, float cy, float cz, float nrho)
+__device__ __forceinline__ float general_filter(int p, const float (&mx)[P], const float (&my)[P], const float (&mz)[P], const float (&fx)[P],
+                                                const float (&fy)[P], const float (&fz)[P], const float (&a0)[P], const float (&o2)[P], float cx, float cy,
+                                                float cz, float kc)
 {
-    const float qx = ox[p] - cx, qy = oy[p] - cy, qz = oz[p] - cz;
-    const float a = __builtin_fmaf(fx[p], qx, __builtin_fmaf(fy[p], qy, fz[p] * qz));
-    const float w = __builtin_fmaf(qx, qx, __builtin_fmaf(qy, qy, __builtin_fmaf(qz, qz, nrho)));
+    const float a = __builtin_fmaf(fx[p], cx, __builtin_fmaf(fy[p], cy, __builtin_fmaf(fz[p], cz, a0[p])));
+    const float w = __builtin_fmaf(mx[p], cx, __builtin_fmaf(my[p], cy, __builtin_fmaf(mz[p], cz, o2[p] + kc)));
     return __builtin_fmaf(a, a, -w);
 }
 
+__device__ __forceinline__ void stage_general(const RenderArgs& A, float* s_gen, int tid, int c0, int cn)
+{
+    for (int i = tid; i < cn; i += kWaves * 64) {
+        const float4 g = A.gen[c0 + i];
+        s_gen[i] = g.x;
+        s_gen[kChunk + i] = g.y;
+        s_gen[2 * kChunk + i] = g.z;
+        s_gen[3 * kChunk + i] = g.w;
+    }
+}
+
 // P rays per lane against the whole list: closest hit (renderer.rs:47-54) -> best_t/best_i.  Sphere data staged per 1024-chunk
-// in LDS (s_gen: cx | cy | cz | -rho).  Must be called by every wave of the workgroup (barriers); `need` selects the live rays.
+// in LDS (s_gen: c'x | c'y | c'z | Kc).  Must be called by every wave of the workgroup (barriers); `need` selects the live rays.
 template <int P>
 __device__ __forceinline__ void trace_general(const RenderArgs& A, float* s_gen, int tid, uint32_t need, const float (&ox)[P],
                                               const float (&oy)[P], const float (&oz)[P], const float (&ux)[P], const float (&uy)[P],
                                               const float (&uz)[P], float (&best_t)[P], int (&best_i)[P])
 {
-    float fx[P], fy[P], fz[P], gx[P], gy[P], gz[P];
+    float fx[P], fy[P], fz[P], gx[P], gy[P], gz[P], a0[P], o2[P];
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         const bool on = (need >> p) & 1u;
         // dead rays get an inert filter: direction 0 and an origin 1e18 away => g = -|q|^2 < 0, never a candidate
-        fx[p] = on ? ux[p] * kGenDirScale : 0.0f;
-        fy[p] = on ? uy[p] * kGenDirScale : 0.0f;
-        fz[p] = on ? uz[p] * kGenDirScale : 0.0f;
-        gx[p] = on ? ox[p] : 1.0e18f;
-        gy[p] = on ? oy[p] : 1.0e18f;
-        gz[p] = on ? oz[p] : 1.0e18f;
+        const float sx = on ? ux[p] * kGenDirScale : 0.0f, sy = on ? uy[p] * kGenDirScale : 0.0f, sz = on ? uz[p] * kGenDirScale : 0.0f;
+        const float px = on ? ox[p] - A.ball[0] : 1.0e18f, py = on ? oy[p] - A.ball[1] : 1.0e18f, pz = on ? oz[p] - A.ball[2] : 1.0e18f;
+        a0[p] = __builtin_fmaf(sx, px, __builtin_fmaf(sy, py, sz * pz));
+        o2[p] = __builtin_fmaf(px, px, __builtin_fmaf(py, py, pz * pz)) * kGenO2Scale;
+        fx[p] = -sx; fy[p] = -sy; fz[p] = -sz;
+        gx[p] = -2.0f * px; gy[p] = -2.0f * py; gz[p] = -2.0f * pz;
         best_i[p] = -1;
         best_t[p] = 0.0f;
     }
@@ -210,13 +227,7 @@ __device__ __forceinline__ void trace_general(const RenderArgs& A, float* s_gen,
     for (int c0 = 0; c0 < A.n_pad; c0 += kChunk) {
         const int cn = min(kChunk, A.n_pad - c0);
         __syncthreads();
-        for (int i = tid; i < cn; i += kWaves * 64) {
-            const float4 g = A.gen[c0 + i];
-            s_gen[i] = g.x;
-            s_gen[kChunk + i] = g.y;
-            s_gen[2 * kChunk + i] = g.z;
-            s_gen[3 * kChunk + i] = g.w;
-        }
+        stage_general(A, s_gen, tid, c0, cn);
         __syncthreads();
         if (__builtin_amdgcn_ballot_w64(need != 0u) == 0ull) continue;  // no live ray in this wave (barriers above still run)
         for (int s0 = 0; s0 < cn; s0 += kGenBlock) {
@@ -236,20 +247,28 @@ __device__ __forceinline__ void trace_general(const RenderArgs& A, float* s_gen,
 #pragma unroll
             for (int b = 0; b < kGenBlock; ++b)
 #pragma unroll
-                for (int p = 0; p < P; ++p) m = __builtin_fmaxf(m, general_filter<P>(p, gx, gy, gz, fx, fy, fz, bx[b], by[b], bz[b], bw[b]));
+                for (int p = 0; p < P; ++p) m = __builtin_fmaxf(m, general_filter<P>(p, gx, gy, gz, fx, fy, fz, a0, o2, bx[b], by[b], bz[b], bw[b]));
             if (__builtin_amdgcn_ballot_w64(m >= 0.0f) == 0ull) continue;
+            // some lane has a candidate in this block (every bounce ray starts ON a sphere, so every wave gets here a few times): the
+            // spheres' exact-test operands are fetched together (one load latency, not one per sphere) and the per-sphere vote re-uses
+            // the constants the block was evaluated from
+            float4 sr[kGenBlock];
+#pragma unroll
+            for (int b = 0; b < kGenBlock; ++b) sr[b] = A.sph_r[c0 + s0 + b];
+#pragma unroll
             for (int b = 0; b < kGenBlock; ++b) {
                 const int k = c0 + s0 + b;
-                const float4 g = A.gen[k];
-                bool cand = false;
-#pragma unroll
-                for (int p = 0; p < P; ++p) cand = cand || (general_filter<P>(p, gx, gy, gz, fx, fy, fz, g.x, g.y, g.z, g.w) >= 0.0f);
-                if (__builtin_amdgcn_ballot_w64(cand) == 0ull) continue;
-                const float4 s = A.sph_r[k];
+                uint32_t slots = 0u;
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
+                    const bool cand = general_filter<P>(p, gx, gy, gz, fx, fy, fz, a0, o2, bx[b], by[b], bz[b], bw[b]) >= 0.0f;
+                    if (__builtin_amdgcn_ballot_w64(cand) != 0ull) slots |= 1u << p;
+                }
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    if (!((slots >> p) & 1u)) continue;  // wave-uniform: none of the 64 rays of this slot is a candidate of sphere k
                     float t;
-                    const bool h = hit_general_exact(ox[p], oy[p], oz[p], ux[p], uy[p], uz[p], s, t) && ((need >> p) & 1u);
+                    const bool h = hit_general_exact(ox[p], oy[p], oz[p], ux[p], uy[p], uz[p], sr[b], t) && ((need >> p) & 1u);
                     take_closest(h, t, k, best_t[p], best_i[p]);
                 }
             }
@@ -662,10 +681,13 @@ __global__ __launch_bounds__(kWaves * 64) void shadow_mask_kernel(const RenderAr
     const uint32_t chunks = ((uint32_t)A.n_lights + LC - 1) / LC;
     const uint32_t n_tiles = groups * chunks;
     const int n_cl = A.n_pad / 16;
+    // Tiles come from the queue TB at a time: returning atomics on ONE address complete at only ~40-80 M/s chip-wide, a rate the small
+    // tiles of this kernel would otherwise be bound by (tiles of either size took 12-14 ns each).  (Giving every wave its first TB
+    // tiles statically, to spare the burst of fetches at the start of the launch, measured 6 % slower: profiles/r03_tuning.md.)
     uint32_t t_next = 0, t_stop = 0;
     for (;;) {
-        if (t_next == t_stop) {  // fetch TB tiles at a time: returning atomics on ONE address complete at ~80 M/s chip-wide, a rate the small
-            uint32_t t0 = 0;     // tiles of this kernel would otherwise be bound by (tiles of either size took 12-14 ns each)
+        if (t_next == t_stop) {
+            uint32_t t0 = 0;
             if (lane == 0) t0 = atomicAdd(A.tile_ctr, (uint32_t)TB);
             t_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)t0);
             t_stop = t_next + TB;
@@ -950,16 +972,9 @@ __global__ __launch_bounds__(kWaves * 64) void shadow_mask_kernel(const RenderAr
 // A ray that misses keeps its colour for good (renderer.rs:47-56: prev_info stays untouched), so its pixel is stored at once and the
 // record is marked dead (rec_idx = -1).  A wave owns 64*P consecutive records (neighbouring pixels: wave votes stay effective).
 template <int P>
-__global__ __launch_bounds__(kWaves * 64) void shade_iter_kernel(const RenderArgs A)
+__device__ __forceinline__ void shade_records(const RenderArgs& A, float* s_buf, int tid, uint32_t count, uint32_t wave_first)
 {
-    __shared__ __attribute__((aligned(16))) float s_buf[4 * kChunk];
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6;
     const int lane = tid & 63;
-    const uint32_t count = *A.rec_count;
-    const uint32_t wg_first = blockIdx.x * (kWaves * 64 * P);
-    if (wg_first >= count) return;  // whole workgroup: no barrier has been executed yet
-    const uint32_t wave_first = wg_first + wave * (64 * P);
     const bool shadows = (A.flags & RT_SHADOWS) != 0u;
     const bool last = A.iter + 1u >= A.depth;  // renderer.rs:67 (i < limit)
     const size_t cap = A.rec_cap;
@@ -1064,6 +1079,20 @@ __global__ __launch_bounds__(kWaves * 64) void shade_iter_kernel(const RenderArg
             A.rec_state[kStCr * cap + r] = cr[p]; A.rec_state[kStCg * cap + r] = cg[p]; A.rec_state[kStCb * cap + r] = cb[p];
         }
     }
+}
+
+// A workgroup owns 4 * 64 * P consecutive records and its waves walk the LDS chunks of the list together (barriers).  (A persistent
+// grid whose waves pull 64 * P-record units from a queue was measured and lost, 0.66 against 0.31 ms on C3 depth 2: returning atomics
+// on one address complete at only ~40-80 M/s chip-wide, and 7168 resident waves all fetch at once; profiles/r03_tuning.md.)
+template <int P>
+__global__ __launch_bounds__(kWaves * 64) void shade_iter_kernel(const RenderArgs A)
+{
+    __shared__ __attribute__((aligned(16))) float s_buf[4 * kChunk];
+    const int tid = threadIdx.x;
+    const uint32_t count = *A.rec_count;
+    const uint32_t wg_first = blockIdx.x * (kWaves * 64 * P);
+    if (wg_first >= count) return;  // whole workgroup: no barrier has been executed yet
+    shade_records<P>(A, s_buf, tid, count, wg_first + (uint32_t)(tid >> 6) * (64 * P));
 }
 
 // Zeroes scratch words with a KERNEL, not hipMemsetAsync: `planes` planes of `n` words, `stride` words apart, starting at p; plus up to
@@ -1218,8 +1247,6 @@ hipError_t launch_primary(RenderArgs a, hipStream_t stream)
     return hipGetLastError();
 }
 }  // namespace
-
-hipError_t clear_scratch_words(uint32_t* q, uint32_t nq, hipStream_t stream) { return clear_words(nullptr, 0, 0, 0, q, nq, stream); }
 
 // The resident-slot caches of the three persistent kernels for the current device (launch_primary / launch_render fill them on first
 // use otherwise): called at context creation so that no render call does set-up work.

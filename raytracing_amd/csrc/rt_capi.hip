@@ -16,6 +16,19 @@
 
 using namespace rtamd;
 
+// The band plan of a multi-device context for one call geometry (multi_plan)
+struct MultiPlan {
+    struct Band { uint32_t b0 = 0, b1 = 0; int part = 0; size_t off = 0, hit_off = 0; };
+    bool valid = false;
+    uint32_t w = 0, y0 = 0, y1 = 0;
+    size_t bpp = 0;
+    bool hit = false;
+    std::vector<Band> bands;      // one per entry of the device list
+    std::vector<size_t> need;     // staging bytes per part
+    std::vector<uint32_t> order;  // non-empty bands, grouped by part
+    std::vector<BandXfer> xfers;  // reused call after call
+};
+
 struct rt_ctx {
     int device = -1;
     hipStream_t stream = nullptr, copy_stream = nullptr;
@@ -76,6 +89,10 @@ struct rt_ctx {
     std::vector<rt_ctx*> parts;   // one single-device context per DISTINCT device of the list; parts[0] is on the root device
     std::vector<int> band_part;   // per band (= entry of the device list): index into parts
     BandGather gather;            // RCCL communicators over the parts (only when there is more than one band)
+    MultiPlan plan;
+    hipStream_t last_root_stream = nullptr;  // the caller stream of the previous call (multi_enqueue orders a call on another stream after it)
+    bool last_root_stream_set = false;
+    hipEvent_t ev_stream_switch = nullptr;
     hipEvent_t ev_multi_end = nullptr;
 };
 
@@ -148,6 +165,9 @@ static hipError_t noalloc_scratch_of_device(int device, unsigned char** out)  //
         const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
         if (e != hipSuccess) return e;
         if (!p) return hipErrorInvalidSymbol;
+        // the tile-queue counters start at zero ONCE: the kernels re-arm them as they end (render_kernel), so no call has to clear them
+        const hipError_t ez = hipMemset(p, 0, kNoAllocRecOffset);
+        if (ez != hipSuccess) return ez;
         g_scratch_ptr[device] = static_cast<unsigned char*>(p);
     }
     *out = g_scratch_ptr[device];
@@ -191,6 +211,23 @@ int32_t rt_debug_prepare_spheres(const rt_objects* o, float* filt, uint8_t* cls)
     if (!o || !filt || !cls || o->n < 0) return RT_ERR_INVALID;
     if (o->n > 0 && (!o->cx || !o->cy || !o->cz || !o->radius)) return RT_ERR_INVALID;
     prepare_filter(o->n, o->cx, o->cy, o->cz, o->radius, reinterpret_cast<f4*>(filt), cls, nullptr);
+    return RT_OK;
+}
+
+int32_t rt_debug_prepare_shadow_cull(const rt_objects* o, const rt_lights* l, int32_t light, int32_t* order, float* lfilt, float* cl_a, float* cl_b,
+                                     int32_t* always, int32_t* n_always)
+{
+    if (!o || !l || !order || !lfilt || !cl_a || !cl_b || !always || !n_always || light < 0 || light >= l->n) return RT_ERR_INVALID;
+    PreparedScene ps;
+    if (!prepare_scene(o, l, ps).empty()) return RT_ERR_INVALID;
+    const size_t np = (size_t)ps.n_pad, ncl = np / kShadowCluster;
+    std::memcpy(order, ps.order.data(), np * sizeof(int32_t));
+    std::memcpy(lfilt, ps.lfilt.data() + (size_t)light * np, np * 16);
+    std::memcpy(cl_a, ps.lclA.data() + (size_t)light * ncl, ncl * 16);
+    std::memcpy(cl_b, ps.lclB.data() + (size_t)light * ncl, ncl * 16);
+    const int32_t a0 = ps.lalways_off[light], a1 = ps.lalways_off[light + 1];
+    *n_always = a1 - a0;
+    if (a1 > a0) std::memcpy(always, ps.lalways.data() + a0, (size_t)(a1 - a0) * sizeof(int32_t));
     return RT_OK;
 }
 
@@ -282,10 +319,12 @@ int32_t rt_ctx_create_multi(rt_ctx** out, const int32_t* device_ids, int32_t n_d
     c->device = device_ids[0];
     std::vector<int> devices;  // distinct, in order of first appearance: devices[0] is the root
     // TEST HOOK: RT_MULTI_SPLIT_PARTS=1 gives every list entry a part of its own even when devices repeat, so that the per-part logic
-    // (own stream, staging, communicator rank) runs on a one-GPU machine.  Real RCCL refuses two ranks on one device: only usable with
-    // the fake RCCL of tests/fake_rccl (RT_RCCL_LIB).
+    // (own stream, staging, communicator rank) runs on a one-GPU machine.  Real RCCL refuses two ranks on one device, so the hook is only
+    // honoured together with an explicitly named RCCL stand-in (RT_RCCL_LIB = the fake RCCL of tests/fake_rccl); a production process
+    // that sets neither variable can never reach it.
     const char* split_env = std::getenv("RT_MULTI_SPLIT_PARTS");
-    const bool split_parts = split_env && split_env[0] == '1';
+    const char* rccl_env = std::getenv("RT_RCCL_LIB");
+    const bool split_parts = split_env && split_env[0] == '1' && rccl_env && rccl_env[0];
     for (int32_t g = 0; g < n_devices; ++g) {
         size_t p = 0;
         while (p < devices.size() && (split_parts || devices[p] != device_ids[g])) ++p;
@@ -304,7 +343,8 @@ int32_t rt_ctx_create_multi(rt_ctx** out, const int32_t* device_ids, int32_t n_d
     {
         DeviceGuard guard(c->device);
         hipError_t e;
-        if ((e = guard.status) != hipSuccess || (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev_multi_end)) != hipSuccess) {
+        if ((e = guard.status) != hipSuccess || (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev_multi_end)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&c->ev_stream_switch, hipEventDisableTiming)) != hipSuccess) {
             const int32_t rc = fail_hip(nullptr, e, "multi-device context setup");
             rt_ctx_destroy(c);
             return rc;
@@ -334,6 +374,7 @@ int32_t rt_ctx_destroy(rt_ctx* c)
             DeviceGuard g(c->device >= 0 ? c->device : 0);
             if (c->ev0) (void)hipEventDestroy(c->ev0);
             if (c->ev_multi_end) (void)hipEventDestroy(c->ev_multi_end);
+            if (c->ev_stream_switch) (void)hipEventDestroy(c->ev_stream_switch);
         }
         for (rt_ctx* p : c->parts) (void)rt_ctx_destroy(p);
         delete c;
@@ -552,13 +593,12 @@ static int32_t enqueue_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h
     char* rec_base = nullptr;
     size_t rec_cap = 0;
     if (kind == ScratchKind::kStatic) {
-        // [tile-queue counters (64 B) | pad to 256 | count (16 B) | planes of npix words]; everything that must start at zero is
-        // cleared on `st` (the counters here; the record count and the occlusion words by launch_render)
+        // [tile-queue counters (64 B) | pad to 256 | count (16 B) | planes of npix words | sort bins]; the counters were zeroed when the
+        // array's address was resolved and re-arm themselves; the record count, occlusion words and sort bins are cleared by launch_render
         if (general && kNoAllocRecOffset + 16 + npix * planes * 4 + (size_t)bin_words * 4 > (size_t)RT_NOALLOC_SCRATCH_BYTES)
             return fail(c, RT_ERR_TOO_LARGE, "rt_render_rows_device_noalloc: this band needs " + std::to_string(kNoAllocRecOffset + 16 + npix * planes * 4 + (size_t)bin_words * 4) +
                                                  " bytes of hit-record scratch, the fixed array holds " + std::to_string((size_t)RT_NOALLOC_SCRATCH_BYTES));
         a.tile_ctr = reinterpret_cast<uint32_t*>(c->noalloc_scratch);
-        RT_HIP(c, clear_scratch_words(a.tile_ctr, 16, st));
         rec_base = reinterpret_cast<char*>(c->noalloc_scratch) + kNoAllocRecOffset;
         rec_cap = npix;
     } else {
@@ -626,58 +666,92 @@ static int32_t enqueue_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h
 // display.rs:99), render band 0 in place in the caller's frame on the root device and every other band into its part's staging, on
 // that part's own stream; then ONE RCCL group gathers the staged bands into their rows of the frame (rt_multi.cpp).  `st_root` is the
 // stream the caller waits on: the receives are enqueued on it, so "st_root idle" means the whole frame has landed.
-static int32_t multi_enqueue(rt_ctx* c, const float m[16], uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t depth, uint32_t flags,
-                             void* d_out, void* d_hit_idx, hipStream_t st_root)
+// The band plan (rows, staging offsets, launch order grouped by device) is cached in the context and rebuilt only when the geometry of
+// the call changes, every device is made current once per call, and nothing is allocated per call (profiles/r03_multi_ctx_probe.txt).
+static void multi_plan(rt_ctx* c, uint32_t w, uint32_t y0, uint32_t y1, size_t bpp, bool hit)
 {
+    MultiPlan& mp = c->plan;
+    if (mp.valid && mp.w == w && mp.y0 == y0 && mp.y1 == y1 && mp.bpp == bpp && mp.hit == hit) return;
     const uint32_t G = (uint32_t)c->band_part.size(), rows = y1 - y0;
-    const size_t bpp = (flags & RT_OUT_RGB8) ? 3 : 4;
-    struct Band { uint32_t b0, b1; int part; size_t off; };
-    std::vector<Band> bands(G);
-    std::vector<size_t> need(c->parts.size(), 0);
+    mp.bands.assign(G, MultiPlan::Band());
+    mp.need.assign(c->parts.size(), 0);
     for (uint32_t g = 0; g < G; ++g) {
-        Band& b = bands[g];
+        MultiPlan::Band& b = mp.bands[g];
         b.b0 = y0 + (uint32_t)((uint64_t)rows * g / G);
         b.b1 = y0 + (uint32_t)((uint64_t)rows * (g + 1) / G);
         b.part = c->band_part[g];
-        b.off = 0;
-        if (g > 0) {
-            b.off = need[(size_t)b.part];
-            need[(size_t)b.part] += ((size_t)(b.b1 - b.b0) * w * (bpp + (d_hit_idx ? 4 : 0)) + 255) / 256 * 256;
+        b.off = b.hit_off = 0;
+        if (g > 0) {  // staged: [pixels | pad to 256 | hit indices | pad to 256] (the hit plane is written with 4-byte stores and sent by RCCL)
+            const size_t npix = (size_t)(b.b1 - b.b0) * w;
+            b.off = mp.need[(size_t)b.part];
+            b.hit_off = b.off + (npix * bpp + 255) / 256 * 256;
+            mp.need[(size_t)b.part] = b.hit_off + (hit ? (npix * 4 + 255) / 256 * 256 : 0);
         }
     }
+    mp.order.clear();  // launch order: part-major, so that every device is made current once
+    for (size_t p = 0; p < c->parts.size(); ++p)
+        for (uint32_t g = 0; g < G; ++g)
+            if ((size_t)mp.bands[g].part == p && mp.bands[g].b1 > mp.bands[g].b0) mp.order.push_back(g);
+    mp.xfers.reserve(2 * (size_t)G);
+    mp.w = w; mp.y0 = y0; mp.y1 = y1; mp.bpp = bpp; mp.hit = hit;
+    mp.valid = true;
+}
+
+static int32_t multi_enqueue(rt_ctx* c, const float m[16], uint32_t w, uint32_t h, uint32_t y0, uint32_t y1, uint32_t depth, uint32_t flags,
+                             void* d_out, void* d_hit_idx, hipStream_t st_root)
+{
+    const size_t bpp = (flags & RT_OUT_RGB8) ? 3 : 4;
+    multi_plan(c, w, y0, y1, bpp, d_hit_idx != nullptr);
+    MultiPlan& mp = c->plan;
     for (size_t p = 0; p < c->parts.size(); ++p) {
         rt_ctx* part = c->parts[p];
-        if (need[p] <= part->d_band_bytes) continue;
+        if (mp.need[p] <= part->d_band_bytes) continue;
         DeviceGuard guard(part->device);
         RT_HIP(c, guard.status);
         RT_HIP(c, hipDeviceSynchronize());  // earlier frames may still be sending out of the old staging
         if (part->d_band) RT_HIP(c, hipFree(part->d_band));
         part->d_band = nullptr;
         part->d_band_bytes = 0;
-        RT_HIP(c, hipMalloc(&part->d_band, need[p]));
-        part->d_band_bytes = need[p];
+        RT_HIP(c, hipMalloc(&part->d_band, mp.need[p]));
+        part->d_band_bytes = mp.need[p];
     }
-    std::vector<BandXfer> xfers;
-    for (uint32_t g = 0; g < G; ++g) {
-        const Band& b = bands[g];
-        if (b.b1 == b.b0) continue;
+    // The root device's staging is reused frame after frame and its bands run on the CALLER's stream: when that stream differs from the
+    // previous call's, order this call after everything the previous stream holds (an event recorded on it now, a stream-level wait
+    // here), or the render of this frame could overwrite staging the previous frame is still sending from.  Nothing is recorded while
+    // the caller stays on one stream.  (The previous stream must still exist: see rt_render_rows_device in the header.)
+    if (c->last_root_stream_set && c->last_root_stream != st_root && c->parts[0]->d_band) {
+        if (hipEventRecord(c->ev_stream_switch, c->last_root_stream) == hipSuccess) RT_HIP(c, hipStreamWaitEvent(st_root, c->ev_stream_switch, 0));
+        else (void)hipGetLastError();
+    }
+    c->last_root_stream = st_root;
+    c->last_root_stream_set = true;
+    mp.xfers.clear();
+    int current = c->device;  // the entry point made the root device current (and restores the caller's when it returns)
+    for (const uint32_t g : mp.order) {
+        const MultiPlan::Band& b = mp.bands[g];
         rt_ctx* part = c->parts[(size_t)b.part];
+        if (part->device != current) {
+            RT_HIP(c, hipSetDevice(part->device));
+            current = part->device;
+        }
         const size_t npix = (size_t)(b.b1 - b.b0) * w, dst_off = (size_t)(b.b0 - y0) * w;
+        // Bands of the root device run on the caller's stream (band 0 in place, repeated entries of the root device into its staging);
+        // every other device's bands on that part's own stream.
         hipStream_t st = b.part == 0 ? st_root : part->stream;
         char* out = g == 0 ? static_cast<char*>(d_out) : static_cast<char*>(part->d_band) + b.off;
-        char* hit = !d_hit_idx ? nullptr : (g == 0 ? static_cast<char*>(d_hit_idx) : out + npix * bpp);
-        {
-            DeviceGuard guard(part->device);
-            RT_HIP(c, guard.status);
-            const int32_t rc = enqueue_rows(part, m, w, h, b.b0, b.b1, depth, flags, out, hit, st);
-            if (rc != RT_OK) return fail(c, rc, part->err);
+        char* hit = !d_hit_idx ? nullptr : (g == 0 ? static_cast<char*>(d_hit_idx) : static_cast<char*>(part->d_band) + b.hit_off);
+        const int32_t rc = enqueue_rows(part, m, w, h, b.b0, b.b1, depth, flags, out, hit, st, ScratchKind::kContext, false);
+        if (rc != RT_OK) {
+            if (current != c->device) (void)hipSetDevice(c->device);
+            return fail(c, rc, part->err);
         }
         if (g > 0) {
-            xfers.push_back(BandXfer{b.part, out, static_cast<char*>(d_out) + dst_off * bpp, npix * bpp, st});
-            if (hit) xfers.push_back(BandXfer{b.part, hit, static_cast<char*>(d_hit_idx) + dst_off * 4, npix * 4, st});
+            mp.xfers.push_back(BandXfer{b.part, out, static_cast<char*>(d_out) + dst_off * bpp, npix * bpp, st});
+            if (hit) mp.xfers.push_back(BandXfer{b.part, hit, static_cast<char*>(d_hit_idx) + dst_off * 4, npix * 4, st});
         }
     }
-    const std::string msg = c->gather.gather(xfers, st_root);
+    if (current != c->device) RT_HIP(c, hipSetDevice(c->device));
+    const std::string msg = c->gather.gather(mp.xfers, st_root);
     if (!msg.empty()) return fail(c, RT_ERR_RCCL, "band gather: " + msg);
     return RT_OK;
 }

@@ -52,6 +52,39 @@ void prepare_filter(int32_t n, const float* cx, const float* cy, const float* cz
     }
 }
 
+// Bounding ball of everything a ray can start from or end at: the sphere surfaces and the camera (0,0,0); the lights are added per
+// light (prepare_light_filters).  Planes are unbounded: they do not shape the ball; hit points outside it take exact paths in the kernel.
+// Its centre is also the point the general-origin filter is expanded around (out.gen).
+static void scene_ball(const rt_objects* o, PreparedScene& out)
+{
+    const int32_t n = o->n;
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    auto fin = [&](int32_t i) {
+        return !(o->kind && o->kind[i] == RT_PLANE) && std::isfinite(o->cx[i]) && std::isfinite(o->cy[i]) && std::isfinite(o->cz[i]) && std::isfinite(o->radius[i]);
+    };
+    for (int32_t i = 0; i < n; ++i) {
+        if (!fin(i)) continue;
+        const double v[3] = {o->cx[i], o->cy[i], o->cz[i]};
+        for (int a = 0; a < 3; ++a) {
+            if (v[a] < lo[a]) lo[a] = v[a];
+            if (v[a] > hi[a]) hi[a] = v[a];
+        }
+    }
+    for (int a = 0; a < 3; ++a) {
+        out.ball[a] = (float)(0.5 * (lo[a] + hi[a]));
+        out.ball_c[a] = out.ball[a];  // the centre exactly as the kernel sees it
+    }
+    auto distC = [&](double x, double y, double z) {
+        return std::sqrt((x - out.ball_c[0]) * (x - out.ball_c[0]) + (y - out.ball_c[1]) * (y - out.ball_c[1]) + (z - out.ball_c[2]) * (z - out.ball_c[2]));
+    };
+    double Rs = distC(0, 0, 0);
+    for (int32_t i = 0; i < n; ++i)
+        if (fin(i)) Rs = std::fmax(Rs, distC(o->cx[i], o->cy[i], o->cz[i]) + std::fabs((double)o->radius[i]));
+    out.ball_r = Rs;
+    // hit points within 0.999 Rs of the centre (in f32 arithmetic) are certainly inside the ball the shadow margins assume
+    out.ball[3] = (float)(0.998 * Rs * Rs);
+}
+
 /*
  * Shadow-ray filter (RT_SHADOWS extension).  A shadow ray runs from a hit point h toward the light at lp with the float
  * direction u = (lp - h)/dist; the kernel tests the reversed line {lp + t w}, w = -u, which has a COMMON origin for all rays
@@ -88,30 +121,12 @@ static void prepare_light_filters(const rt_objects* o, const rt_lights* l, Prepa
     out.lclB.assign((size_t)nl * ncl, f4{2.0f, 0, 0, 0});
     out.lalways.clear();
     out.lalways_off.assign(nl + 1, 0);
-    // bounding ball of everything a ray can start from or end at: sphere surfaces, the camera (0,0,0), the lights
-    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-    auto grow = [&](double x, double y, double z) {
-        const double v[3] = {x, y, z};
-        for (int a = 0; a < 3; ++a) {
-            if (v[a] < lo[a]) lo[a] = v[a];
-            if (v[a] > hi[a]) hi[a] = v[a];
-        }
-    };
     std::vector<char> fin(n, 0);
     auto is_plane = [&](int32_t i) { return o->kind && o->kind[i] == RT_PLANE; };
-    for (int32_t i = 0; i < n; ++i) {
-        // planes are unbounded: they do not shape the ball; their far hit points are handled exactly by the kernel (out.ball)
-        fin[i] = !is_plane(i) && std::isfinite(o->cx[i]) && std::isfinite(o->cy[i]) && std::isfinite(o->cz[i]) && std::isfinite(o->radius[i]);
-        if (fin[i]) grow(o->cx[i], o->cy[i], o->cz[i]);
-    }
-    const double C[3] = {0.5 * (lo[0] + hi[0]), 0.5 * (lo[1] + hi[1]), 0.5 * (lo[2] + hi[2])};
-    auto distC = [&](double x, double y, double z) { return std::sqrt((x - C[0]) * (x - C[0]) + (y - C[1]) * (y - C[1]) + (z - C[2]) * (z - C[2])); };
-    double Rs = distC(0, 0, 0);
     for (int32_t i = 0; i < n; ++i)
-        if (fin[i]) Rs = std::fmax(Rs, distC(o->cx[i], o->cy[i], o->cz[i]) + std::fabs((double)o->radius[i]));
-    // hit points within 0.999 Rs of C (in f32 arithmetic) are certainly inside the ball the margins below assume
-    out.ball[0] = (float)C[0]; out.ball[1] = (float)C[1]; out.ball[2] = (float)C[2];
-    out.ball[3] = (float)(0.998 * Rs * Rs);
+        fin[i] = !is_plane(i) && std::isfinite(o->cx[i]) && std::isfinite(o->cy[i]) && std::isfinite(o->cz[i]) && std::isfinite(o->radius[i]);
+    const double C[3] = {out.ball_c[0], out.ball_c[1], out.ball_c[2]}, Rs = out.ball_r;
+    auto distC = [&](double x, double y, double z) { return std::sqrt((x - C[0]) * (x - C[0]) + (y - C[1]) * (y - C[1]) + (z - C[2]) * (z - C[2])); };
     const double P1 = 1.0 - 64.0 * u;
     std::vector<double> th_s(kShadowCluster), ex(kShadowCluster), ey(kShadowCluster), ez(kShadowCluster);
     for (int32_t m = 0; m < nl; ++m) {
@@ -275,10 +290,11 @@ std::string prepare_scene(const rt_objects* o, const rt_lights* l, PreparedScene
     out.filt.assign(out.n_pad, f4{0, 0, 0, 0});
     out.sph.assign(out.n_pad, f4{0, 0, 0, inf});
     out.sph_r.assign(out.n_pad, f4{0, 0, 0, NAN});
-    out.gen.assign(out.n_pad, f4{0, 0, 0, inf});  // -rho = +inf: W = +inf, g = -inf, never a candidate
+    out.gen.assign(out.n_pad, f4{0, 0, 0, inf});  // Kc = +inf: W = +inf, g = -inf, never a candidate
     out.refl.assign(out.n_pad, f4{0, 0, 0, 0});
     out.pln.assign(out.n_pad, f4{0, 0, 0, 0});
     out.cls.assign(o->n, 0);
+    scene_ball(o, out);
     std::vector<float> k(o->n);
     prepare_filter(o->n, o->cx, o->cy, o->cz, o->radius, out.filt.data(), out.cls.data(), k.data());
     for (int32_t i = 0; i < o->n; ++i) {
@@ -296,12 +312,20 @@ std::string prepare_scene(const rt_objects* o, const rt_lights* l, PreparedScene
         out.sph[i] = f4{o->cx[i], o->cy[i], o->cz[i], k[i]};
         out.sph_r[i] = f4{o->cx[i], o->cy[i], o->cz[i], o->radius[i]};
         {
-            // general-origin filter (render_kernels.hip): rho = fl(r*r) (1+eta)/(1-eta), eta = 2^-17, rounded up
-            const double eta = std::ldexp(1.0, -17);
+            // general-origin filter (render_kernels.hip: general_filter): rho = fl(r*r) (1+eta)/(1-eta), eta = 2^-17, rounded up;
+            // c' = c - B as f32; Kc = |c'|^2 (1 - 64u) - rho, rounded DOWN (a smaller W can only add candidates).  Non-finite data
+            // gives Kc = NaN or +-inf: g is then NaN (never >= 0) exactly where the reference's own arithmetic yields NaN (a miss).
+            const double eta = std::ldexp(1.0, -17), u64 = std::ldexp(1.0, -18);
             const float r2 = o->radius[i] * o->radius[i];  // the reference's own rounded r*r (sphere.rs:29)
             float rho = (float)((double)r2 * (1.0 + eta) / (1.0 - eta));
             rho = std::nextafter(rho, INFINITY);
-            out.gen[i] = f4{o->cx[i], o->cy[i], o->cz[i], -rho};
+            const float gx = (float)((double)o->cx[i] - out.ball_c[0]), gy = (float)((double)o->cy[i] - out.ball_c[1]), gz = (float)((double)o->cz[i] - out.ball_c[2]);
+            const double c2 = (double)gx * gx + (double)gy * gy + (double)gz * gz;
+            float kc = (float)(c2 * (1.0 - u64) - (double)rho);
+            kc = std::nextafter(kc, -INFINITY);
+            // absurd scales (squares near the f32 range): always a candidate, the exact test decides
+            if (std::fabs(gx) > 1e15f || std::fabs(gy) > 1e15f || std::fabs(gz) > 1e15f || std::fabs(o->radius[i]) > 1e15f) kc = -INFINITY;
+            out.gen[i] = f4{gx, gy, gz, kc};
         }
         out.refl[i] = f4{o->refl_r[i], o->refl_g[i], o->refl_b[i], 0.0f};
         if (!out.cls[i]) out.always.push_back(i);

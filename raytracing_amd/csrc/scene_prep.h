@@ -27,12 +27,13 @@ struct PreparedScene {
     std::vector<f4> filt;        // n_pad: (cx', cy', cz', 0) — conservative primary-ray filter d.c' - 1 >= 0 ; (0,0,0,0) = never passes
     std::vector<f4> sph;         // n_pad: (cx, cy, cz, k) with k = dot3(c,c) - r*r in the reference's order (sphere.rs:29 with origin 0)
     std::vector<f4> sph_r;       // n_pad: (cx, cy, cz, radius) for general-origin rays (bounces, shadow rays)
-    std::vector<f4> gen;         // n_pad: (cx, cy, cz, -rho), rho = r*r (1+eta)/(1-eta) rounded up: general-origin filter
+    std::vector<f4> gen;         // n_pad: (c'x, c'y, c'z, Kc), c' = c - ball centre, Kc = |c'|^2 (1 - 64u) - rho: general-origin filter
     std::vector<f4> refl;        // n_pad: Material.reflectiveness (element.rs:18), w unused
     std::vector<int32_t> always; // indices of spheres the filter cannot cover (origin inside / on / absurd values): tested exactly for every pixel
     std::vector<uint8_t> cls;    // n: 1 = filterable sphere, 0 = sphere always tested exactly, 2 = plane
     std::vector<f4> pln;         // n_pad: (nx, ny, nz, 1) for RT_PLANE elements, 0 otherwise
     std::vector<int32_t> planes; // indices of the RT_PLANE elements: tested exactly for every ray (no filter)
+    double ball_c[3] = {0, 0, 0}, ball_r = 0;  // the same centre (as doubles of the f32 values) and the full radius Rs
     float ball[4] = {0, 0, 0, 0}; // centre and squared radius of the ball the shadow filters were derived for (hit points outside it
                                   // — possible only on planes — take the exact path)
     std::vector<f4> lpos;        // n_lights: (px, py, pz, intensity)

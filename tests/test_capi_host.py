@@ -123,6 +123,92 @@ def test_primary_filter_is_conservative(oracle, seed):
     assert (f[cls == 1] >= 0).sum() <= 8
 
 
+@pytest.mark.parametrize("seed", [1, 2])
+def test_shadow_hierarchy_is_conservative(oracle, seed):
+    """RT_SHADOWS any-hit hierarchy (scene_prep.cpp: prepare_light_filters; render_kernels.hip: shadow_mask_kernel), emulated in f32:
+    for groups of shadow rays as a wave holds them, (1) every blocker the ORACLE reports is a candidate of the per-ray filter or on the
+    light's always-list, (2) every filter candidate passes the member cone test and its cluster passes the cluster cone test, (3) the
+    cluster of every blocker passes the length test.  So the votes never drop a sphere the walk over the whole list would have tested."""
+    f32 = np.float32
+    w, h, n = 96, 54, 300
+    objs, _ = scenegen.generate(w, h, n, 1, seed=seed)
+    rng = np.random.default_rng(100 + seed)
+    lp_all = np.array([[0.5, 1.0, -6.0], [-3.0, 2.0, -14.0], [4.0, -2.0, -9.0]], np.float32)
+    # awkward spheres: the light inside, on the surface, just outside; a huge and a tiny one
+    extra = np.array([[0.5, 1.0, -6.2, 0.5], [-3.0, 2.0, -13.0, 1.0], [4.0, -2.0, -9.6, 0.55], [0, 0, -60, 25.0], [1, 1, -5, 1e-3]], np.float32)
+    cx = np.concatenate([objs.cx, extra[:, 0]]); cy = np.concatenate([objs.cy, extra[:, 1]])
+    cz = np.concatenate([objs.cz, extra[:, 2]]); rad = np.concatenate([objs.radius, extra[:, 3]])
+    one = np.ones_like(cx)
+    allo = capi.FlatObjects(cx, cy, cz, rad, one, one, one)
+    nl = len(lp_all)
+    lights = capi.FlatLights(lp_all[:, 0], lp_all[:, 1], lp_all[:, 2], np.ones(nl), np.ones(nl), np.ones(nl), np.ones(nl))
+    C_ = np.stack([cx, cy, cz], 1)
+    P1 = f32(1.0) - f32(3.814697265625e-06)
+    blockers = cand_total = listed = groups = 0
+    for li in range(nl):
+        d = capi.debug_prepare_shadow_cull(allo, lights, li)
+        order, lf, cla, clb, always = d["order"], d["lfilt"], d["cl_a"], d["cl_b"], set(int(a) for a in d["always"])
+        assert sorted(order[order >= 0]) == list(range(allo.n))
+        entry = (lf[:, :3] != 0).any(1)
+        assert all((order[j] in always) != bool(entry[j]) for j in range(len(order)) if order[j] >= 0)
+        lp = lp_all[li]
+        for g in range(14):
+            # a wave's rays: hit points on one sphere (sometimes two neighbours in the spatial order), facing anywhere
+            j0 = int(rng.integers(0, allo.n))
+            members = [order[j0]] + ([order[min(allo.n - 1, j0 + 1)]] if g % 3 == 0 else [])
+            nrm = rng.normal(size=(128, 3)); nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+            ks = rng.choice(members, size=128)
+            hpt = (C_[ks] + nrm * rad[ks][:, None]).astype(f32)
+            v = (lp[None, :] - hpt).astype(f32)
+            sd = np.sqrt(((v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1]).astype(f32) + (v[:, 2] * v[:, 2]).astype(f32)).astype(f32)).astype(f32)
+            u = (v / sd[:, None]).astype(f32)
+            wv = (-u).astype(f32)
+            # the kernel's cone
+            a = wv.sum(0, dtype=f32)
+            an = np.sqrt((a * a).sum(dtype=f32), dtype=f32)
+            a = (a / an).astype(f32)
+            c = (wv * a).sum(1, dtype=f32)
+            cr = np.cross(a.astype(np.float64), wv.astype(np.float64)).astype(f32)
+            smax = f32(np.sqrt((cr * cr).sum(1, dtype=f32), dtype=f32).max())
+            cmin, sdmax = f32(c.min()), f32(sd.max())
+            wide = not (an > 0 and np.isfinite(an) and cmin > 0.5)
+            sinT = f32(smax * f32(1.0 + 1.0e-6) + f32(1.0e-6))
+            cosT = f32(np.sqrt(max(f32(0), f32(1.0) - sinT * sinT), dtype=f32) * f32(1.0 - 1.0e-6))
+            # per-ray filter over all positions
+            f = _fma32(wv[:, 0:1], lf[None, :, 0], _fma32(wv[:, 1:2], lf[None, :, 1], _fma32(wv[:, 2:3], lf[None, :, 2], f32(-1.0))))
+            cand = (f >= 0) & entry[None, :]
+            # member and cluster votes as the kernel evaluates them
+            mdot = _fma32(a[0], lf[:, 0], _fma32(a[1], lf[:, 1], f32(a[2] * lf[:, 2])))
+            mrhs = _fma32(cosT, P1, -(sinT * lf[:, 3]).astype(f32))
+            mpass = entry & (wide | (mdot >= mrhs - f32(8.0e-6)))
+            cdot = _fma32(a[0], cla[:, 0], _fma32(a[1], cla[:, 1], f32(a[2] * cla[:, 2])))
+            crhs = _fma32(cosT, clb[:, 0], -(sinT * clb[:, 1]).astype(f32))
+            cdir = wide | (cdot >= crhs - f32(4.0e-6))
+            clen = ~(cla[:, 3] > sdmax)
+            rays, pos = np.nonzero(cand)
+            cand_total += len(rays)
+            assert mpass[pos].all(), "a filter candidate failed the member cone test"
+            assert cdir[pos // 16].all(), "the cluster of a filter candidate failed the cluster cone test"
+            listed += int((mpass & np.repeat(cdir & clen, 16)).sum())
+            groups += 1
+            # oracle blockers of a few rays against every sphere
+            inv = np.full(allo.n, -1)
+            inv[order[order >= 0]] = np.nonzero(order >= 0)[0]
+            for r_ in range(0, 128, 16):
+                for k in range(allo.n):
+                    t = oracle.sphere_is_hit_by(hpt[r_], u[r_], C_[k], float(rad[k]))
+                    if t is None or not (t > capi.RT_SHADOW_EPS and t < sd[r_]):
+                        continue
+                    blockers += 1
+                    if k in always:
+                        continue
+                    j = inv[k]
+                    assert f[r_, j] >= 0, "the per-light filter missed a blocker"
+                    assert clen[j // 16], "the length test dropped the cluster of a blocker"
+    assert blockers > 50 and cand_total > 200
+    assert listed / groups < 0.25 * allo.n, "the hierarchy is a useful filter"
+
+
 def test_scenegen_is_deterministic_and_pinned():
     o1, l1 = scenegen.generate(3840, 2160, 1024, 4)
     o2, l2 = scenegen.generate(3840, 2160, 1024, 4)

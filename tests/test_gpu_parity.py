@@ -698,6 +698,37 @@ def test_multi_device_context_virtual_bands(oracle):
         capi.Context(device_ids=[])
 
 
+def test_multi_device_context_alternating_caller_streams(oracle):
+    """A multi-device context whose device list repeats the ROOT device ([0] * 4) called with a different caller stream every frame, and
+    with changing scenes' brightness so that a stale band would show: the staged bands of the root device are rendered and sent on the
+    part's own stream, so frame N + 1's render into the staging is ordered after frame N's send out of it whatever the caller's
+    streams are (they used to run on the caller's stream of each call)."""
+    import torch
+    w, h = 1920, 1080
+    objs, lights = scenegen.generate(w, h, 600, 3, seed=9)
+    m = _cam(oracle, w, h)
+    variants = []
+    for k in range(3):
+        lk = capi.FlatLights(lights.px, lights.py, lights.pz, lights.cr, lights.cg, lights.cb, lights.intensity * np.float32(1.0 + 0.5 * k))
+        variants.append(lk)
+    refs = []
+    with capi.Context(0) as one:
+        for lk in variants:
+            one.scene_upload(objs, lk)
+            refs.append(one.render(m, w, h, 1, 0))
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    with capi.Context(device_ids=[0] * 4) as ctx:
+        for rep in range(2):
+            for k, lk in enumerate(variants):
+                ctx.scene_upload(objs, lk)  # (synchronises the devices of the context)
+                frames = [torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda") for _ in range(6)]
+                for i, f in enumerate(frames):  # six frames in flight, the caller's stream changes every frame
+                    ctx.render_rows_device(m, w, h, 0, h, 1, 0, f.data_ptr(), 0, streams[i % 3].cuda_stream)
+                torch.cuda.synchronize()
+                for i, f in enumerate(frames):
+                    _assert_same(f.cpu().numpy(), refs[k], f"rep {rep} scene {k} frame {i} on alternating caller streams")
+
+
 def test_multi_device_through_host_mirrors(tmp_path):
     """examples/main with RT_DEVICES=0,0,0 (a process without torch: the library loads RCCL itself) and the Python Renderer mirror with
     a device list both write the reference's result.png."""
