@@ -21,13 +21,20 @@ def run(ctx, label):
     for _ in range(100):
         ctx.render_rows_device(m, w, h, 0, h, 1, 0, out.data_ptr(), 0, st.cuda_stream)
     st.synchronize()
+    per = []
     t0 = time.perf_counter()
     for _ in range(frames):
+        a = time.perf_counter()
         ctx.render_rows_device(m, w, h, 0, h, 1, 0, out.data_ptr(), 0, st.cuda_stream)
+        per.append(time.perf_counter() - a)
     t1 = time.perf_counter()
     st.synchronize()
     t2 = time.perf_counter()
-    print("%-28s host %.1f us per call, %.4f ms per frame" % (label, (t1 - t0) / frames * 1e6, (t2 - t0) / frames * 1e3), flush=True)
+    per = np.array(per) * 1e6
+    # the MEDIAN is the cost of issuing a call; the mean also holds the calls that blocked because the device's queue was full (the
+    # host runs ahead of the GPU in this loop, so with enough frames it is throttled to the GPU's frame time)
+    print("%-28s host median %.1f us per call (p10 %.1f, p90 %.1f, mean %.1f), %.4f ms per frame" %
+          (label, np.median(per), np.percentile(per, 10), np.percentile(per, 90), (t1 - t0) / frames * 1e6, (t2 - t0) / frames * 1e3), flush=True)
 
 
 with capi.Context(0) as c:
