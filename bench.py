@@ -330,11 +330,23 @@ def main():
         my_tests = (y1 - y0) * w * objs.n
         kernels = [("render_kernel<primary>" if not general else "render_kernel<emit>", my_tests, FLOPS_PER_TEST, kern_ms if not general else phase_ms[0],
                     "%d per (pixel,sphere) filter test x %d tests per launch" % (FLOPS_PER_TEST, my_tests))]
+        shadow_info = None
         if general and args.shadows:
-            sh_tests = n_hits * n_point * objs.n * args.depth
-            kernels.append(("shadow_mask_kernel", sh_tests, FLOPS_PER_SHADOW_TEST, phase_ms[1],
-                            "%d per (shadow ray,sphere) filter test x %d hit records x %d point lights x %d spheres x %d iteration(s): an upper bound, "
-                            "the any-hit early-out skips tests and later iterations hold fewer live records" % (FLOPS_PER_SHADOW_TEST, n_hits, n_point, objs.n, args.depth)))
+            # shadow_mask_kernel: its any-hit hierarchy tests only the spheres a wave's rays can reach, so the work is data-dependent:
+            # the executed flops are the counter-derived figure of the committed PMC pass of this command (None without one); the
+            # no-early-out bound (every shadow ray against every sphere with the 3-FMA filter) is reported beside it
+            bound = FLOPS_PER_SHADOW_TEST * n_hits * n_point * objs.n * args.depth
+            pv, pnote = pmc_summary(args.config, args.depth, True, "shadow_mask_kernel")
+            sh_flops = pv.get("flops") if pv else None
+            shadow_info = {"no_early_out_bound_flops": bound, "executed_flops": sh_flops,
+                           "executed_over_bound": (sh_flops / bound) if sh_flops else None,
+                           "lane_utilisation": pv.get("lane_utilisation") if pv else None,
+                           "source": ("counter-derived flops " + pnote) if sh_flops else pnote}
+            kernels.append(("shadow_mask_kernel (+ record sort)", 1, sh_flops or 0.0, phase_ms[1],
+                            ("counter-derived: 64 x (2 FMA + ADD + MUL + TRANS) of the committed PMC pass = %.4g flops per launch, %.3f of the no-early-out bound "
+                             "(%d per (shadow ray,sphere) filter test x %d hit records x %d point lights x %d spheres x %d iteration(s))" %
+                             (sh_flops, sh_flops / bound, FLOPS_PER_SHADOW_TEST, n_hits, n_point, objs.n, args.depth)) if sh_flops else
+                            "executed flops unknown (%s); no-early-out bound %.4g" % (pnote, bound)))
         if general and args.depth > 1:
             bo_tests = n_hits * objs.n * (args.depth - 1)
             kernels.append(("shade_iter_kernel (shading + trace_general)", bo_tests, FLOPS_PER_BOUNCE_TEST, phase_ms[2],
@@ -385,8 +397,9 @@ def main():
                                    "kernels": [{"kernel": k_[0], "ms": k_[3], "TFLOP/s": (k_[1] * k_[2] / (k_[3] * 1e-3) / 1e12) if k_[3] > 0 else None,
                                                 "frac": (k_[1] * k_[2] / (k_[3] * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS) if k_[3] > 0 else None,
                                                 "flops_counted": k_[4]} for k_ in kernels],
+                                   "shadow_any_hit": shadow_info,
                                    "rays_per_step": w * h + (n_hits * n_point * args.depth if args.shadows else 0) + n_hits * (args.depth - 1),
-                                   "note": "value counts primary rays only; rays_per_step adds the shadow and bounce rays (upper bounds, see flops_counted)"}
+                                   "note": "value counts primary rays only; rays_per_step adds the shadow and bounce rays (upper bounds: later iterations hold fewer live records)"}
         out["roofline"]["traffic"], out["roofline"]["traffic_note"] = pmc_traffic(args.config, args.depth, args.shadows, dom[0])
         if diag is not None:
             out["diagnostics"] = diag
@@ -472,18 +485,19 @@ def kernel_source_sha256():
     return hsh.hexdigest()
 
 
-def pmc_traffic(config, depth=1, shadows=False, kernel="render_kernel<primary>"):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS command (profiles/r02_<tag>_pmc.txt,
-    written by tools/summarize_prof.py: TCC_EA0_WRREQ x 64 B + TCC_EA0_RDREQ x 64 B x 2, the gfx950 correction of MI355X_MICROARCH.md).
-    Counters cannot be read inside an unprofiled run, so this is the value of the profiled run of the same command — and only if
-    the summary was taken with the kernel sources this build comes from (its `kernel source sha256` line); otherwise None + a note."""
+def pmc_summary(config, depth=1, shadows=False, kernel="render_kernel<primary>"):
+    """Figures of the committed rocprofv3 PMC passes of THIS command for one kernel (profiles/r03_<tag>_pmc.txt, written by
+    tools/summarize_prof.py): HBM bytes per launch (TCC_EA0_WRREQ x 64 B + TCC_EA0_RDREQ x 64 B x 2, the gfx950 correction of
+    MI355X_MICROARCH.md) and the counter-derived f32 flops per launch.  Counters cannot be read inside an unprofiled run, so these are
+    the values of the profiled run of the same command — and only if the summary was taken with the kernel sources this build comes
+    from (its `kernel source sha256` line).  Returns (dict or None, note)."""
     tag = config.lower() + ("_depth%d" % depth if depth > 1 else "") + ("_shadows" if shadows else "")
-    path = os.path.join(ROOT, "profiles", "r02_%s_pmc.txt" % tag)
+    path = os.path.join(ROOT, "profiles", "r03_%s_pmc.txt" % tag)
     if not os.path.exists(path):
         return None, "no PMC pass committed for this command (%s)" % os.path.basename(path)
     want = "render_kernel<16, false>" if kernel == "render_kernel<primary>" else ("render_kernel<16, true>" if kernel == "render_kernel<emit>" else kernel.split(" ")[0])
     sha = None
-    wr = rd = None
+    vals = {}
     inside = False
     for line in open(path):
         if line.startswith("kernel source sha256"):
@@ -491,14 +505,23 @@ def pmc_traffic(config, depth=1, shadows=False, kernel="render_kernel<primary>")
         elif line.startswith("## "):
             inside = want in line
         elif inside and line.startswith("HBM write bytes"):
-            wr = float(line.rsplit("=", 1)[1])
+            vals["wr"] = float(line.rsplit("=", 1)[1])
         elif inside and line.startswith("HBM read bytes"):
-            rd = float(line.rsplit("=", 1)[1])
+            vals["rd"] = float(line.rsplit("=", 1)[1])
+        elif inside and line.startswith("counter-derived f32 flops per dispatch"):
+            vals["flops"] = float(line.rsplit("=", 1)[1])
+        elif inside and line.startswith("VALU lane utilisation"):
+            vals["lane_utilisation"] = float(line.rsplit("=", 1)[1])
     if sha != kernel_source_sha256():
         return None, "%s was taken with other kernel sources (sha256 %s...): stale, not reported" % (os.path.basename(path), (sha or "none")[:12])
-    if wr is None or rd is None:
+    if "wr" not in vals or "rd" not in vals:
         return None, "%s has no HBM lines for %s" % (os.path.basename(path), want)
-    return wr + rd, "bytes per launch of %s, from %s (separate --pmc passes of this command, same kernel sources)" % (want, os.path.relpath(path, ROOT))
+    return vals, "per launch of %s, from %s (separate --pmc passes of this command, same kernel sources)" % (want, os.path.relpath(path, ROOT))
+
+
+def pmc_traffic(config, depth=1, shadows=False, kernel="render_kernel<primary>"):
+    vals, note = pmc_summary(config, depth, shadows, kernel)
+    return (vals["wr"] + vals["rd"], "bytes " + note) if vals else (None, note)
 
 
 def cpu_baseline(objs, lights, m, w, h, depth=1, flags=0):

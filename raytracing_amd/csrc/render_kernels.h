@@ -56,6 +56,9 @@ struct RenderArgs {
     uint32_t static_grid;             // 1: plain grid, workgroup b renders tile b only (small bands); 0: persistent grid + tile queue
 };
 
+// One tile-queue counter slot (A.tile_ctr): word 0 = next tile, word 1 = workgroups (waves) that have left; 64 B apart.
+constexpr uint32_t kTileSlotWords = 16;
+
 // How launch_render cuts a band of `rows` rows x `w` columns into the tile queue of the persistent primary kernel, given the number of
 // resident workgroup slots: 64-pixel strips; the first rows4 rows in 16-row tiles, the next rows2 in 8-row tiles, the rest in 4-row tiles
 // (rows past the band's end are masked in the kernel).  Host-only; exposed for the CPU tests (rt_debug_tile_plan).

@@ -880,9 +880,6 @@ __global__ __launch_bounds__(kWaves * 64) void shadow_mask_kernel(const RenderAr
                         return true;
                     };
                     bool going = true;
-#ifdef RT_MASK_SKIP_WIDE  // DEV timing experiment only (wrong image): what do the wide waves cost?
-                    if (wide) going = false;
-#endif
                     for (int cb = 0; cb < n_cl && going; cb += 256) {
                         // ---- cluster vote: four clusters per lane, their loads in flight together; open clusters -> s_cl ----
                         float4 ca[4], cs[4];

@@ -152,7 +152,7 @@ struct DeviceGuard {
 // until the process ends.  In host code the NAME `scratch` is only a stand-in for HIP_SYMBOL(); the address a kernel, a memset or a copy
 // can use is the one hipGetSymbolAddress returns with that device current, looked up once per device (rt_ctx_create) and kept here.
 static __device__ __align__(256) unsigned char scratch[RT_NOALLOC_SCRATCH_BYTES];
-static constexpr size_t kNoAllocRecOffset = 256;  // [0, 64): tile-queue counters; [256, ...): hit-record count + planes
+static constexpr size_t kNoAllocRecOffset = kTileSlotWords * 4 < 256 ? 256 : kTileSlotWords * 4;  // [0, slot): tile-queue counters; then the hit-record count + planes
 
 static unsigned char* g_scratch_ptr[64] = {};  // per device; a benign race: concurrent callers store the same value
 
@@ -273,8 +273,8 @@ int32_t rt_ctx_create(rt_ctx** out, int32_t device_id)
         (e = hipEventCreate(&c->ev0)) != hipSuccess || (e = hipEventCreate(&c->ev_dev_end)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->ev_general, hipEventDisableTiming)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking)) != hipSuccess || (e = hipEventCreate(&c->ev_host_end)) != hipSuccess ||
-        (e = hipMalloc(reinterpret_cast<void**>(&c->d_tile_ctr), kTileSlots * 64)) != hipSuccess ||
-        (e = hipMemset(c->d_tile_ctr, 0, kTileSlots * 64)) != hipSuccess) {
+        (e = hipMalloc(reinterpret_cast<void**>(&c->d_tile_ctr), kTileSlots * kTileSlotWords * 4)) != hipSuccess ||
+        (e = hipMemset(c->d_tile_ctr, 0, kTileSlots * kTileSlotWords * 4)) != hipSuccess) {
         int32_t rc = fail_hip(nullptr, e, "context setup");
         rt_ctx_destroy(c);
         return rc;
@@ -604,7 +604,7 @@ static int32_t enqueue_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h
     } else {
         const int32_t rc = take_tile_slot(c, st, slot);
         if (rc != RT_OK) return rc;
-        a.tile_ctr = c->d_tile_ctr + (size_t)slot * 16;
+        a.tile_ctr = c->d_tile_ctr + (size_t)slot * kTileSlotWords;
         if (general) {
             // scratch: [count (16 B) | pix | idx | t | 9 state planes (depth > 1) | occlusion planes (RT_SHADOWS)], planes of rec_capacity words
             if (npix > c->rec_capacity || planes > c->rec_planes || bin_words > c->rec_bin_words) {  // grow (the previous launches that used it must be finished first)

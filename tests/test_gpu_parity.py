@@ -155,6 +155,21 @@ def test_shadows_extension(gpu_ctx, oracle):
     _assert_same(gpu2, ref2, "shadows depth 2")
 
 
+def _tail_sections_vs_oracle(oracle, objs, lights, m, w, h, gpu, hit, flags, what):
+    """The primary kernel cuts a frame into 16-row tiles, then (last 2 %) 8-row tiles, then 4-row tiles (plan_tiles): compare the first
+    8 rows of the 8-row section and the whole 4-row section (the last 8 to 16 rows of the frame) with the oracle, so that every tile
+    shape is checked at this configuration's list length."""
+    plan = capi.tile_plan(w, h, 1024)
+    assert plan["tiles2"] > 0 and plan["tiles1"] > 0, "a whole frame of a BASELINE config uses all three tile shapes"
+    spans = [(plan["rows4"], plan["rows4"] + 8), (plan["rows4"] + plan["rows2"], h)]
+    assert spans[0][1] <= plan["rows4"] + plan["rows2"] and 0 < h - spans[1][0] <= 32
+    for y0, y1 in spans:
+        ref, ref_hit = oracle.render(objs, lights, m, w, h, y0=y0, y1=y1, flags=flags & 1, want_hit_idx=True)
+        _assert_same(gpu[y0:y1], ref, f"{what} rows {y0}:{y1} (tail tile sections)")
+        if hit is not None:
+            assert np.array_equal(hit[y0:y1], ref_hit)
+
+
 def test_c3_full_size_sampled_rows(gpu_ctx, oracle):
     """Config 3 at full size (3840x2160, 1024 spheres, 4 lights): every 24th row vs the oracle, plus whole-frame properties."""
     w, h, objs, lights = scenegen.config("C3")
@@ -164,6 +179,7 @@ def test_c3_full_size_sampled_rows(gpu_ctx, oracle):
     ref, ref_hit = oracle.render(objs, lights, m, w, h, row_step=24, want_hit_idx=True)
     _assert_same(gpu[::24], ref[::24], "C3 sampled rows")
     assert np.array_equal(hit[::24], ref_hit[::24])
+    _tail_sections_vs_oracle(oracle, objs, lights, m, w, h, gpu, hit, 0, "C3")
     # size-independent properties: misses are black, hits index a real element, alpha is opaque, bands re-assemble
     assert (gpu[..., 3] == 255).all()
     assert not gpu[hit < 0][:, :3].any()
@@ -378,6 +394,7 @@ def test_c4_c5_full_size_sampled_rows(gpu_ctx, oracle):
     ref, ref_hit = oracle.render(objs, lights, m, w, h, row_step=540, want_hit_idx=True)
     _assert_same(gpu[::540], ref[::540], "C4 sampled rows")
     assert np.array_equal(hit[::540], ref_hit[::540])
+    _tail_sections_vs_oracle(oracle, objs, lights, m, w, h, gpu, hit, 0, "C4")  # the 8-chunk list in the 8- and 4-row tile shapes
     assert (gpu[..., 3] == 255).all() and not gpu[hit < 0][:, :3].any() and hit.max() < objs.n
     del gpu, hit
     w, h, objs, lights = scenegen.config("C5")
@@ -387,6 +404,7 @@ def test_c4_c5_full_size_sampled_rows(gpu_ctx, oracle):
     shadowed = gpu_ctx.render(m, w, h, 1, capi.RT_SHADOWS)
     ref = oracle.render(objs, lights, m, w, h, row_step=360, flags=1)
     _assert_same(shadowed[::360], ref[::360], "C5 shadows sampled rows")
+    _tail_sections_vs_oracle(oracle, objs, lights, m, w, h, shadowed, None, capi.RT_SHADOWS, "C5 shadows")
     # occlusion only removes light: no channel gets brighter, background stays black, something does get darker
     assert (shadowed[..., :3] <= lit[..., :3]).all()
     assert (shadowed[..., :3] < lit[..., :3]).any()

@@ -172,6 +172,40 @@ def test_plane_extension_known_answers(oracle):
         oracle.render(capi.FlatObjects([0], [0], [-5], [0], [1], [1], [1], kind=np.array([1], np.uint8)), lights, m, 8, 8)  # plane without normals
 
 
+# (position, versor (r, i, j, k), scale, v, expected f32 bit patterns of Transform::apply): the first is exact by hand — the versor
+# (1/2, 1/2, 1/2, 1/2) maps (x, y, z) to (z, x, y), so (1, 2, 3) -> (3, 1, 2) + (0.5, -1.25, 2) = (3.5, -0.25, 4); the last is a
+# 45-degree turn about y; the middle two carry rounding in every lane
+KNOWN_TRANSFORM = [
+    ((0.5, -1.25, 2.0), (0.5, 0.5, 0.5, 0.5), (1.0, 1.0, 1.0), (1.0, 2.0, 3.0), [0x40600000, 0xBE800000, 0x40800000]),
+    ((1.0, 2.0, 3.0), (0.8, 0.6, 0.0, 0.0), (2.0, 0.5, 1.5), (0.3, -0.7, 1.1), [0x3FCCCCCD, 0x3FAFDF3B, 0x401D0E56]),
+    ((-3.0, 0.25, 7.0), (0.18257419, 0.36514837, 0.54772256, 0.73029674), (0.1, 0.1, 0.1), (10.0, -20.0, 30.0), [0xBFDDDDE0, 0x40655553, 0x40BBBBBC]),
+    ((0.0, 0.0, 0.0), (0.9238795, 0.0, 0.38268343, 0.0), (1.0, 1.0, 1.0), (1.0, 0.0, 0.0), [0x3F3504F3, 0x00000000, 0xBF3504F3]),
+]
+
+
+def _quat_mul_np(a, b):
+    """quat.rs:205-224, one numpy f32 operation per SIMD statement (swizzles as index lists)."""
+    f = np.float32
+    a, b = np.asarray(a, f), np.asarray(b, f)
+    t1 = a[[1, 1, 2, 3]] * b[[1, 0, 0, 0]]
+    t2 = a[[2, 2, 3, 1]] * b[[2, 3, 1, 2]]
+    t12m = (t1 + t2) * np.array([-1, 1, 1, 1], f)
+    t3 = a[[3, 3, 1, 2]] * b[[3, 2, 3, 1]]
+    t03 = a[[0, 0, 0, 0]] * b - t3
+    return (t03 + t12m).astype(f)
+
+
+def _transform_apply_np(pos, q, scl, v):
+    """math/mod.rs:40-43 with Versor::apply (quat.rs:159-166): p = (0, v) by the swizzle [3, 0, 1, 2] of a Vec3 whose lane 3 is 0."""
+    f = np.float32
+    v4 = np.array([v[0], v[1], v[2], 0], f)
+    p = v4[[3, 0, 1, 2]]
+    inv = np.asarray(q, f) * np.array([1, -1, -1, -1], f)  # conjugate
+    res = _quat_mul_np(_quat_mul_np(q, p), inv)
+    rot = res[[1, 2, 3, 0]][:3]
+    return (np.asarray(pos, f) + rot * np.asarray(scl, f)).astype(f)
+
+
 def test_transform_apply_matches_the_reference_formula(oracle):
     """Transform::apply (math/mod.rs:40-43) = position + Versor::apply(v) (x) scale (quat.rs:159-166, 201-226): the library's
     host helper is bit-identical to the oracle's restatement; both agree with a float64 rotation to rounding; known rotations.
@@ -184,14 +218,23 @@ def test_transform_apply_matches_the_reference_formula(oracle):
         q = (q / np.linalg.norm(q)).astype(f)
         pos, scl, v = (rng.standard_normal(3) * 5).astype(f), (rng.random(3) * 3 + 0.1).astype(f), (rng.standard_normal(3) * 10).astype(f)
         got = capi.transform_apply(pos, q, scl, v)
-        ref = oracle.transform_apply(pos, q, scl, v)
-        assert got.tobytes() == ref.tobytes()
+        # an independent restatement (numpy f32 lanes and swizzles, written from quat.rs:205-224): the library's `hamilton` and the
+        # oracle's `quat_mul` share their text, so comparing those two with each other would prove nothing
+        want_bits = _transform_apply_np(pos, q, scl, v)
+        assert got.tobytes() == want_bits.tobytes()
+        assert oracle.transform_apply(pos, q, scl, v).tobytes() == want_bits.tobytes()
         r, i, j, k = [float(x) for x in q]
         rot = np.array([[1 - 2 * (j * j + k * k), 2 * (i * j - k * r), 2 * (i * k + j * r)],
                         [2 * (i * j + k * r), 1 - 2 * (i * i + k * k), 2 * (j * k - i * r)],
                         [2 * (i * k - j * r), 2 * (j * k + i * r), 1 - 2 * (i * i + j * j)]])
         want = pos.astype(np.float64) + (rot @ v.astype(np.float64)) * scl.astype(np.float64)
         assert np.allclose(got, want, rtol=0, atol=2e-5 * (1 + np.abs(want).max()))
+    # known answers (f32 bit patterns): KNOWN_TRANSFORM below, worked out lane by lane with the restatement above and checked against a
+    # float64 rotation matrix; a change that breaks `hamilton` and `quat_mul` the same way fails here
+    for pos, q, scl, v, bits in KNOWN_TRANSFORM:
+        got = capi.transform_apply(f(pos), f(q), f(scl), f(v))
+        assert [int(x) for x in got.view(np.uint32)] == bits, (pos, q, got)
+        assert [int(x) for x in oracle.transform_apply(f(pos), f(q), f(scl), f(v)).view(np.uint32)] == bits
     h = f(np.sqrt(0.5))
     quarter_z = (h, 0, 0, h)  # 90 degrees about z: x -> y
     assert np.allclose(capi.transform_apply((0, 0, 0), quarter_z, (1, 1, 1), (1, 0, 0)), (0, 1, 0), atol=1e-6)

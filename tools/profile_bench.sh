@@ -1,7 +1,7 @@
 #!/bin/bash
 # Profile one bench.py command on the GPU box: kernel trace + stats, then PMC passes (each in its own run, no other tracing).
 # Usage: tools/profile_bench.sh <tag> [bench.py args...]   e.g.  tools/profile_bench.sh c3_depth2 --config C3 --depth 2
-# Then on the CPU side: python tools/summarize_prof.py gpurun_out/prof_<tag> profiles/r02_<tag>
+# Then on the CPU side: python tools/summarize_prof.py gpurun_out/prof_<tag> profiles/r03_<tag>
 set -e
 TAG=$1; shift
 cd /tmp && export TMPDIR=/tmp

@@ -6,7 +6,7 @@ import sqlite3
 import sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
-dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r02_c3"
+dst = sys.argv[2] if len(sys.argv) > 2 else "profiles/r03_c3"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402  (kernel_source_sha256: ties the summary to the kernel sources it was taken with)
 os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
@@ -18,8 +18,18 @@ lines.append("# rocprofv3 --kernel-trace --stats (top_kernels view of the rocpd 
 lines.append("# kernel, calls, total_us, average_us, percent")
 for name, calls, total, avg, pct in con.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
     lines.append(f"\"{name[:140]}\",{calls},{total:.3f},{avg:.3f},{pct:.3f}")
-row = con.execute("select grid_size_x, grid_size_y, workgroup_size_x, lds_block_size, vgpr_count, accum_vgpr_count, sgpr_count, scratch_size "
-                  "from rocpd_kernel_dispatch d join kernel_symbols k on 1=1 limit 0").fetchall() if False else None
+# Which launches do those averages cover?  top_kernels averages EVERY launch of the run: bench.py's priming and warm-up steps, the
+# timed steps and, for the general path, the launches after the timed region that read the per-kernel events.  The second table gives,
+# per rtamd kernel, the same figures over the last 60 % of its launches (steady state: clocks up, past priming and warm-up).
+lines.append("# per rtamd kernel: all launches (priming + warm-up + timed + post-run probes) vs the last 60 % of its launches (steady state)")
+lines.append("# kernel, launches, mean_us_all, median_us_all, launches_steady, mean_us_steady, median_us_steady")
+per = {}
+for name, dur in con.execute("select name, duration from kernels where name like '%rtamd%' order by start"):
+    per.setdefault(name, []).append(dur / 1000.0)
+for name, d in per.items():
+    sd = d[int(len(d) * 0.4):]
+    srt, ssd = sorted(d), sorted(sd)
+    lines.append(f"\"{name[:140]}\",{len(d)},{sum(d) / len(d):.3f},{srt[len(srt) // 2]:.3f},{len(sd)},{sum(sd) / len(sd):.3f},{ssd[len(ssd) // 2]:.3f}")
 cmd = ""
 try:
     cmd = open(os.path.join(src, "command.txt")).read().strip()
@@ -30,7 +40,7 @@ lines.insert(1, "kernel source sha256 = " + bench.kernel_source_sha256())
 open(dst + "_kernel_stats.csv", "w").write("\n".join(lines) + "\n")
 out = ["# rocprofv3 --pmc passes, averages per dispatch, one block per rtamd kernel", "# command: " + cmd,
        "kernel source sha256 = " + bench.kernel_source_sha256(),
-       "# (VGPRs below is rocprofv3's vgpr_count column; the code object's allocation is in profiles/r02_kernel_resource_usage.txt)", ""]
+       "# (VGPRs below is rocprofv3's vgpr_count column; the code object's allocation is in profiles/r03_kernel_resource_usage.txt)", ""]
 per_kernel = {}
 for f in sorted(glob.glob(os.path.join(src, "pmc_*", "c3_results.db"))):
     c = sqlite3.connect(f)
