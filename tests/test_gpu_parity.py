@@ -354,6 +354,63 @@ def test_fuzz_scenes_cameras_modes(gpu_ctx, oracle):
     print(f"fuzz: {case + 1} scenes, {npix} pixels compared, {nlit} with a hit")
 
 
+def test_shadow_hierarchy_fuzz(gpu_ctx, oracle):
+    """RT_SHADOWS on scenes built to stress the any-hit hierarchy of shadow_mask_kernel (spatial record sort, wave cones, cluster /
+    member / length votes): dense and clustered sphere clouds with thousands of hit records, radii from specks to spheres that fill the
+    view, lights just outside / on / inside surfaces (wide cones, always-lists), far lights (thin cones), overlapping spheres, depth 1-2,
+    a plane now and then (far hit points).  Every image and hit plane byte-equal to the oracle.  RT_SHADOW_FUZZ_CASES / _SEED widen it."""
+    rng = np.random.default_rng(int(os.environ.get("RT_SHADOW_FUZZ_SEED", "31")))
+    f = np.float32
+    nrec = 0
+    for case in range(int(os.environ.get("RT_SHADOW_FUZZ_CASES", "24"))):
+        w, h = int(rng.integers(200, 420)), int(rng.integers(120, 260))
+        n = int(rng.choice([12, 60, 250, 700, 1300]))
+        nl = int(rng.integers(1, 7)) if case % 6 else int(rng.integers(33, 40))
+        spread = f(rng.choice([4.0, 12.0]))
+        k = int(rng.integers(1, 6))  # clusters of spheres
+        cc = rng.standard_normal((k, 3)) * spread * np.array([1.0, 0.6, 0.5]) + np.array([0, 0, -2.2 * spread])
+        which = rng.integers(0, k, n)
+        c = (cc[which] + rng.standard_normal((n, 3)) * spread * rng.choice([0.1, 0.35, 0.8])).astype(f)
+        rad = (rng.random(n) ** 3 * spread * 0.25 + 1e-3).astype(f)
+        if case % 4 == 1:
+            rad[0] = f(spread * 1.5)  # one sphere that fills much of the view
+        refl = (rng.random((3, n)) * 1.2).astype(f)
+        objs = capi.FlatObjects(c[:, 0], c[:, 1], c[:, 2], rad, refl[0], refl[1], refl[2])
+        lp = (rng.standard_normal((nl, 3)) * spread * 1.5 + np.array([0, 0, -1.5 * spread])).astype(f)
+        for i in range(nl):  # most lights relative to a sphere: just outside, on, inside its surface; some far away
+            mode = rng.integers(0, 6)
+            j = int(rng.integers(0, n))
+            d = rng.standard_normal(3); d /= np.linalg.norm(d)
+            if mode == 0:
+                lp[i] = c[j] + d * rad[j] * f(rng.choice([1.0005, 1.02, 1.3]))
+            elif mode == 1:
+                lp[i] = c[j] + d * rad[j]
+            elif mode == 2:
+                lp[i] = c[j] + d * rad[j] * f(rng.random() * 0.9)
+            elif mode == 3:
+                lp[i] = (d * spread * 60).astype(f)
+        kind = (rng.random(nl) < 0.15).astype(np.uint8)
+        lc = rng.random((3, nl)).astype(f)
+        inten = (rng.random(nl) * spread * spread * 3).astype(f)
+        lights = capi.FlatLights(lp[:, 0], lp[:, 1], lp[:, 2], lc[0], lc[1], lc[2], inten, kind=kind)
+        if case % 5 == 4:
+            objs = _with_planes(objs, [((0.0, float(-spread), 0.0), (0.0, 1.0, 0.05), (0.5, 0.5, 0.5))])
+        m = oracle.camera_transform(f(rng.uniform(0.6, 1.4)), f(0.01), f(1000.0), f(w) / f(h))
+        depth = 1 + case % 2
+        flags = capi.RT_SHADOWS | (capi.RT_OUT_RGB8 if case % 7 == 0 else 0)
+        gpu_ctx.scene_upload(objs, lights)
+        gpu, hit = gpu_ctx.render_rows(m, w, h, 0, h, depth, flags, want_hit_idx=True)
+        ref, ref_hit = oracle.render(objs, lights, m, w, h, depth=depth, flags=1, channels=3 if flags & 2 else 4, want_hit_idx=True)
+        _assert_same(gpu, ref, f"shadow fuzz case {case}: {w}x{h} n={objs.n} l={nl} depth={depth}")
+        assert np.array_equal(hit, ref_hit)
+        lit = gpu_ctx.render_rows(m, w, h, 0, h, depth, flags & ~capi.RT_SHADOWS)[0]
+        nrec += int((hit >= 0).sum())
+        if depth == 1:
+            assert (gpu[..., :3] <= lit[..., :3]).all()  # occlusion only removes light
+    assert nrec > 200000
+    print(f"shadow fuzz: {case + 1} scenes, {nrec} hit records")
+
+
 def test_wavefront_many_lights_depth_and_bands(gpu_ctx, oracle):
     """General-ray kernels (shadow_mask_kernel + shade_iter_kernel): more than 32 lights (two occlusion words per record) with ambient
     lights in between, depth 3 with shadows, row bands, and the scratch planes reused across calls with different needs."""
