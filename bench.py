@@ -24,7 +24,7 @@ if ROOT not in sys.path:
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 FLOPS_PER_TEST = 6             # the hot loop executes three v_fma_f32 per (pixel, sphere) pair (render_kernels.h)
 FLOPS_PER_SHADOW_TEST = 6      # shadow_mask_kernel: the same 3-FMA filter per (shadow ray, sphere) with per-light constants
-FLOPS_PER_BOUNCE_TEST = 15     # trace_general: 7 FMA + 1 add per (bounce ray, sphere) = 8 VALU ops (round 2: 10 ops, 16 flops)
+FLOPS_PER_BOUNCE_TEST = 14     # trace_general: 7 FMAs per (bounce ray, sphere) (round 2: 10 operations, 16 flops)
 
 
 def main():

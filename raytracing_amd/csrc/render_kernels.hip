@@ -160,7 +160,7 @@ __device__ __forceinline__ void shade(const RenderArgs& A, bool active, int k, f
 // expanded around the scene centre B (A.ball) so that no per-pair subtraction is left:  o' = o - B, c' = c - B,
 //     a' = u'.o' - u'.c'                    = fma(-u'x, c'x, fma(-u'y, c'y, fma(-u'z, c'z, A0)))       A0 = u'.o'   (per ray)
 //     W  = |o'|^2 - 2 o'.c' + |c'|^2 - rho  = fma(-2o'x, c'x, fma(-2o'y, c'y, fma(-2o'z, c'z, O2 + Kc)))
-//     g  = fma(a', a', -W)                                                   7 FMAs + 1 add per (ray, sphere), 15 flops
+//     g  = fma(a', a', -W)    evaluated as  h = fma(a', a', -(W - O2)) >= O2         7 FMAs per (ray, sphere), 14 flops
 // Margins: u' = u (1 + 2^-16) and rho = r^2 (1+eta)/(1-eta), eta = 2^-17, cover the difference between fused and unfused evaluation of
 // the reference's expression (< 48 u (|q|^2 + r^2), u = 2^-24) as before; the expansion adds cancellation error <= 52 u (|o'|^2 + |c'|^2)
 // (roundings of o', c', O2, Kc, the sum and the seven FMAs), covered per ray by O2 = |o'|^2 (1 - 64u) and per sphere by
@@ -172,14 +172,15 @@ constexpr float kGenO2Scale = 1.0f - 3.814697265625e-06f;  // 1 - 64u
 #endif
 constexpr int kGenBlock = RT_GEN_BLOCK;                    // spheres per wave vote in the general loops
 
+// h(ray, sphere) = a'^2 - T with T = W - O2: the pair is a candidate iff h >= O2 (= g >= 0), so the per-ray term O2 never enters the
+// per-pair arithmetic: 7 FMAs per (ray, sphere), and the block vote compares each ray's maximum of h with its own O2.
 template <int P>
 __device__ __forceinline__ float general_filter(int p, const float (&mx)[P], const float (&my)[P], const float (&mz)[P], const float (&fx)[P],
-                                                const float (&fy)[P], const float (&fz)[P], const float (&a0)[P], const float (&o2)[P], float cx, float cy,
-                                                float cz, float kc)
+                                                const float (&fy)[P], const float (&fz)[P], const float (&a0)[P], float cx, float cy, float cz, float kc)
 {
     const float a = __builtin_fmaf(fx[p], cx, __builtin_fmaf(fy[p], cy, __builtin_fmaf(fz[p], cz, a0[p])));
-    const float w = __builtin_fmaf(mx[p], cx, __builtin_fmaf(my[p], cy, __builtin_fmaf(mz[p], cz, o2[p] + kc)));
-    return __builtin_fmaf(a, a, -w);
+    const float t = __builtin_fmaf(mx[p], cx, __builtin_fmaf(my[p], cy, __builtin_fmaf(mz[p], cz, kc)));
+    return __builtin_fmaf(a, a, -t);
 }
 
 __device__ __forceinline__ void stage_general(const RenderArgs& A, float* s_gen, int tid, int c0, int cn)
@@ -243,12 +244,16 @@ __device__ __forceinline__ void trace_general(const RenderArgs& A, float* s_gen,
                 bz[g] = vz.x; bz[g + 1] = vz.y; bz[g + 2] = vz.z; bz[g + 3] = vz.w;
                 bw[g] = vw.x; bw[g + 1] = vw.y; bw[g + 2] = vw.z; bw[g + 3] = vw.w;
             }
-            float m = -1.0f;
+            float m[P];
+            bool any = false;
 #pragma unroll
-            for (int b = 0; b < kGenBlock; ++b)
+            for (int p = 0; p < P; ++p) {
+                m[p] = -INFINITY;
 #pragma unroll
-                for (int p = 0; p < P; ++p) m = __builtin_fmaxf(m, general_filter<P>(p, gx, gy, gz, fx, fy, fz, a0, o2, bx[b], by[b], bz[b], bw[b]));
-            if (__builtin_amdgcn_ballot_w64(m >= 0.0f) == 0ull) continue;
+                for (int b = 0; b < kGenBlock; ++b) m[p] = __builtin_fmaxf(m[p], general_filter<P>(p, gx, gy, gz, fx, fy, fz, a0, bx[b], by[b], bz[b], bw[b]));
+                any = any || m[p] >= o2[p];
+            }
+            if (__builtin_amdgcn_ballot_w64(any) == 0ull) continue;
             // some lane has a candidate in this block (every bounce ray starts ON a sphere, so every wave gets here a few times): the
             // spheres' exact-test operands are fetched together (one load latency, not one per sphere) and the per-sphere vote re-uses
             // the constants the block was evaluated from
@@ -261,7 +266,7 @@ __device__ __forceinline__ void trace_general(const RenderArgs& A, float* s_gen,
                 uint32_t slots = 0u;
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
-                    const bool cand = general_filter<P>(p, gx, gy, gz, fx, fy, fz, a0, o2, bx[b], by[b], bz[b], bw[b]) >= 0.0f;
+                    const bool cand = general_filter<P>(p, gx, gy, gz, fx, fy, fz, a0, bx[b], by[b], bz[b], bw[b]) >= o2[p];
                     if (__builtin_amdgcn_ballot_w64(cand) != 0ull) slots |= 1u << p;
                 }
 #pragma unroll
