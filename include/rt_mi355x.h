@@ -116,7 +116,8 @@ int32_t rt_transform_apply(const float position[3], const float versor[4], const
 
 /*
  * Replaces the borrow of self.elements / self.lights at renderer.rs:37-38: copies the flattened scene to the device and
- * precomputes the per-sphere constants the kernels use.  May be called again to replace the scene.
+ * precomputes the per-sphere constants the kernels use.  May be called again to replace the scene.  At most 2^22 - 1 elements
+ * (RT_ERR_INVALID beyond); for RT_SHADOWS the device keeps 20 bytes per (point light, element) of filter constants.
  */
 int32_t rt_scene_upload(rt_ctx* ctx, const rt_objects* objects, const rt_lights* lights);
 
