@@ -93,6 +93,35 @@ def test_empty_scene_and_no_lights(gpu_ctx, oracle):
     _assert_same(gpu, ref, "no lights")
 
 
+def test_general_path_degenerate_scenes(gpu_ctx, oracle):
+    """depth > 1 and RT_SHADOWS on scenes that leave parts of the general path with nothing to do: no elements, no lights, ambient lights
+    only (nothing casts a shadow ray), planes only (no sphere list, every hit point outside the scene ball), one sphere, every pixel a
+    hit (the camera inside a sphere), no pixel a hit.  Images and hit planes byte-equal to the oracle."""
+    f = np.float32
+    z = np.zeros(0, f)
+    w, h = 97, 45
+    m = _cam(oracle, w, h)
+    one = lambda *v: np.array(v, f)
+    point = capi.FlatLights(one(0.5, -3), one(2.0, 1), one(-1.0, -6), one(1, 0.5), one(1, 0.7), one(1, 0.9), one(8, 30))
+    ambient = capi.FlatLights(one(0, 0), one(0, 0), one(0, 0), one(0.2, 0.1), one(0.3, 0.1), one(0.1, 0.4), one(0, 0), kind=np.array([1, 1], np.uint8))
+    none_l = capi.FlatLights(z, z, z, z, z, z, z)
+    none_o = capi.FlatObjects(z, z, z, z, z, z, z)
+    single = capi.FlatObjects(one(0.3), one(-0.2), one(-4), one(1.2), one(0.9), one(0.8), one(0.7))
+    inside = capi.FlatObjects(one(0, 1.5), one(0, 0), one(0, -3), one(50, 0.7), one(0.9, 0.5), one(0.8, 0.6), one(0.7, 0.9))  # the camera sits in the first
+    behind = capi.FlatObjects(one(0, 2), one(0, 1), one(5, 9), one(1, 2), one(1, 1), one(1, 1), one(1, 1))               # nothing in view
+    planes = _with_planes(none_o, [((0.0, -1.0, 0.0), (0.0, 1.0, 0.0), (0.8, 0.8, 0.8)), ((0.0, 0.0, -9.0), (0.0, 0.1, 1.0), (0.5, 0.9, 0.5))])
+    cases = [("no elements", none_o, point), ("no lights", single, none_l), ("ambient only", single, ambient), ("planes only", planes, point),
+             ("one sphere", single, point), ("camera inside a sphere", inside, point), ("nothing in view", behind, point),
+             ("nothing at all", none_o, none_l)]
+    for name, objs, lights in cases:
+        gpu_ctx.scene_upload(objs, lights)
+        for depth, flags in ((1, capi.RT_SHADOWS), (2, 0), (3, capi.RT_SHADOWS), (2, capi.RT_SHADOWS | capi.RT_OUT_RGB8)):
+            gpu, hit = gpu_ctx.render_rows(m, w, h, 0, h, depth, flags, want_hit_idx=True)
+            ref, ref_hit = oracle.render(objs, lights, m, w, h, depth=depth, flags=flags & 1, channels=3 if flags & 2 else 4, want_hit_idx=True)
+            _assert_same(gpu, ref, f"{name}: depth {depth} flags {flags}")
+            assert np.array_equal(hit, ref_hit), f"{name}: hit plane, depth {depth} flags {flags}"
+
+
 def test_edge_case_spheres(gpu_ctx, oracle):
     """Camera inside a sphere, on its surface, sphere behind the camera, huge/tiny radii, saturating colours, duplicates (ties)."""
     f = np.float32
