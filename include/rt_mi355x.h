@@ -160,9 +160,9 @@ int32_t rt_render_rows_device(rt_ctx* ctx, const float m[16], uint32_t w, uint32
  * rt_render_rows_device, but the call allocates and frees nothing: the kernels' scratch (tile-queue counters; for depth > 1 or
  * RT_SHADOWS the dense hit records) lives in a fixed array of RT_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds from
  * load to process exit.  Primary-only launches (depth == 1, no RT_SHADOWS) fit at any size; a general launch needs
- * 272 + 4 * P * (y1 - y0) * w bytes, P = 3 + (depth > 1 ? 9 : 0) + (RT_SHADOWS ? ceil(n_lights / 32) + 4 : 0), plus 4 * (n + 4) bytes of
- * sort bins with RT_SHADOWS (n = elements of the scene), and is refused with RT_ERR_TOO_LARGE beyond (e.g. shadows with <= 32 lights:
- * 1.04 Mpixel per call; depth 2: 699 kpixel; cut larger frames into row bands).
+ * 272 + 4 * (n + 4) + 4 * P * (y1 - y0) * w bytes, P = 7 + (depth > 1 ? 9 : 0) + (RT_SHADOWS ? ceil(n_lights / 32) : 0), n = elements of
+ * the scene, and is refused with RT_ERR_TOO_LARGE beyond (e.g. shadows with <= 32 lights: 1.04 Mpixel per call; depth 2: 524 kpixel; cut
+ * larger frames into row bands).
  * All calls on one GPU — of any context, of any thread — share that GPU's array: calls that overlap in time on one GPU race; order
  * them (one stream, or events).  Does not update rt_last_kernel_ms.  Capturable: everything the call enqueues is a kernel launch (the
  * scratch is cleared by a kernel too), so a HIP graph captured around it replays to the same bytes (tests/test_zz_no_alloc.py).

@@ -16,7 +16,8 @@ struct RenderArgs {
     const float4* filt;     // n_pad
     const float4* sph;      // n_pad (cx,cy,cz,k)
     const float4* sph_r;    // n_pad (cx,cy,cz,radius)
-    const float4* gen;      // n_pad (cx,cy,cz,-rho): general-origin filter constants
+    const float4* gen_o;    // n_pad, SPATIAL order: (c'x, c'y, c'z, Kc) general-origin filter constants (c' = c - ball centre)
+    const float4* gcl;      // n_pad / 16: per cluster of 16 consecutive positions (centre c', radius of the centres + largest member radius; -1 = empty)
     const float4* refl;     // n_pad
     const int32_t* always;  // n_always
     const float4* lpos;     // n_lights
@@ -42,11 +43,12 @@ struct RenderArgs {
     float* rec_t;
     uint32_t rec_cap;     // capacity (records) of every rec_* plane
     uint32_t iter;        // iteration of renderer.rs:46 the general-ray kernels work on (set by launch_render)
+    uint32_t sorted;      // this iteration's rec_perm / rec_hit / rec_count[1] are valid (set by launch_render)
     float* rec_state;     // depth > 1: 9 planes of rec_cap floats (origin, direction, colour of the bounce ray); else null
     uint32_t* rec_occ;    // RT_SHADOWS: ceil(n_lights / 32) planes of rec_cap words, occlusion bit per (record, light); else null
-    uint32_t* rec_perm;   // RT_SHADOWS: rec_cap words, the live records of this iteration in spatial order (rec_count[1] entries); else null
-    float* rec_hit;       // RT_SHADOWS: 3 planes of rec_cap floats, the hit points of those records in the same (sorted) order; else null
-    uint32_t* sort_bins;  // RT_SHADOWS: n + 1 words, histogram / running offsets of the record sort; else null
+    uint32_t* rec_perm;   // RT_SHADOWS or depth > 1: rec_cap words, the live records of this iteration in spatial order (rec_count[1] entries); else null
+    float* rec_hit;       // RT_SHADOWS or depth > 1: 3 planes of rec_cap floats, the hit points of those records in the same (sorted) order; else null
+    uint32_t* sort_bins;  // RT_SHADOWS or depth > 1: n + 1 words, histogram / running offsets of the record sort; else null
     // tile queue of the persistent primary kernel: tile_ctr[0] = next tile, tile_ctr[1] = workgroups that have left (library-owned,
     // zero between launches); the rest is filled in by launch_render
     uint32_t* tile_ctr;
@@ -86,9 +88,9 @@ hipError_t prime_launch_caches();
 // True if launch_render needs the rec_* scratch buffers for these args (depth > 1 or RT_SHADOWS).
 bool render_needs_records(const RenderArgs& args);
 
-// Which optional scratch these args need beside count/pix/idx/t: rec_state (9 float planes), rec_occ (occ_words planes) and, with
-// occ_words > 0, four more planes (rec_perm, rec_hit x 3) plus bin_words words of sort bins.
-void render_scratch_layout(const RenderArgs& args, bool& need_state, uint32_t& occ_words, uint32_t& bin_words);
+// Which optional scratch these args need beside count/pix/idx/t: rec_state (9 float planes), rec_occ (occ_words planes), sort_planes
+// more planes (rec_perm, rec_hit x 3) and bin_words words of sort bins.
+void render_scratch_layout(const RenderArgs& args, bool& need_state, uint32_t& occ_words, uint32_t& sort_planes, uint32_t& bin_words);
 
 // Name of the kernel variant launch_render picks for these args (for profiles / bench output).
 const char* render_kernel_name(const RenderArgs& args);

@@ -183,104 +183,6 @@ __device__ __forceinline__ float general_filter(int p, const float (&mx)[P], con
     return __builtin_fmaf(a, a, -t);
 }
 
-__device__ __forceinline__ void stage_general(const RenderArgs& A, float* s_gen, int tid, int c0, int cn)
-{
-    for (int i = tid; i < cn; i += kWaves * 64) {
-        const float4 g = A.gen[c0 + i];
-        s_gen[i] = g.x;
-        s_gen[kChunk + i] = g.y;
-        s_gen[2 * kChunk + i] = g.z;
-        s_gen[3 * kChunk + i] = g.w;
-    }
-}
-
-// P rays per lane against the whole list: closest hit (renderer.rs:47-54) -> best_t/best_i.  Sphere data staged per 1024-chunk
-// in LDS (s_gen: c'x | c'y | c'z | Kc).  Must be called by every wave of the workgroup (barriers); `need` selects the live rays.
-template <int P>
-__device__ __forceinline__ void trace_general(const RenderArgs& A, float* s_gen, int tid, uint32_t need, const float (&ox)[P],
-                                              const float (&oy)[P], const float (&oz)[P], const float (&ux)[P], const float (&uy)[P],
-                                              const float (&uz)[P], float (&best_t)[P], int (&best_i)[P])
-{
-    float fx[P], fy[P], fz[P], gx[P], gy[P], gz[P], a0[P], o2[P];
-#pragma unroll
-    for (int p = 0; p < P; ++p) {
-        const bool on = (need >> p) & 1u;
-        // dead rays get an inert filter: direction 0 and an origin 1e18 away => g = -|q|^2 < 0, never a candidate
-        const float sx = on ? ux[p] * kGenDirScale : 0.0f, sy = on ? uy[p] * kGenDirScale : 0.0f, sz = on ? uz[p] * kGenDirScale : 0.0f;
-        const float px = on ? ox[p] - A.ball[0] : 1.0e18f, py = on ? oy[p] - A.ball[1] : 1.0e18f, pz = on ? oz[p] - A.ball[2] : 1.0e18f;
-        a0[p] = __builtin_fmaf(sx, px, __builtin_fmaf(sy, py, sz * pz));
-        o2[p] = __builtin_fmaf(px, px, __builtin_fmaf(py, py, pz * pz)) * kGenO2Scale;
-        fx[p] = -sx; fy[p] = -sy; fz[p] = -sz;
-        gx[p] = -2.0f * px; gy[p] = -2.0f * py; gz[p] = -2.0f * pz;
-        best_i[p] = -1;
-        best_t[p] = 0.0f;
-    }
-    for (int a = 0; a < A.n_planes; ++a) {  // planes: no filter, exact test for every live ray
-        const int k = A.planes[a];
-        const float4 p0 = A.sph_r[k], n = A.pln[k];
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            float t;
-            const bool h = hit_plane_exact(ox[p], oy[p], oz[p], ux[p], uy[p], uz[p], p0, n, t) && ((need >> p) & 1u);
-            take_closest(h, t, k, best_t[p], best_i[p]);
-        }
-    }
-    for (int c0 = 0; c0 < A.n_pad; c0 += kChunk) {
-        const int cn = min(kChunk, A.n_pad - c0);
-        __syncthreads();
-        stage_general(A, s_gen, tid, c0, cn);
-        __syncthreads();
-        if (__builtin_amdgcn_ballot_w64(need != 0u) == 0ull) continue;  // no live ray in this wave (barriers above still run)
-        for (int s0 = 0; s0 < cn; s0 += kGenBlock) {
-            float bx[kGenBlock], by[kGenBlock], bz[kGenBlock], bw[kGenBlock];
-#pragma unroll
-            for (int g = 0; g < kGenBlock; g += 4) {  // wave-uniform addresses: broadcast ds_read_b128, four spheres per read
-                const float4 vx = *reinterpret_cast<const float4*>(&s_gen[s0 + g]);
-                const float4 vy = *reinterpret_cast<const float4*>(&s_gen[kChunk + s0 + g]);
-                const float4 vz = *reinterpret_cast<const float4*>(&s_gen[2 * kChunk + s0 + g]);
-                const float4 vw = *reinterpret_cast<const float4*>(&s_gen[3 * kChunk + s0 + g]);
-                bx[g] = vx.x; bx[g + 1] = vx.y; bx[g + 2] = vx.z; bx[g + 3] = vx.w;
-                by[g] = vy.x; by[g + 1] = vy.y; by[g + 2] = vy.z; by[g + 3] = vy.w;
-                bz[g] = vz.x; bz[g + 1] = vz.y; bz[g + 2] = vz.z; bz[g + 3] = vz.w;
-                bw[g] = vw.x; bw[g + 1] = vw.y; bw[g + 2] = vw.z; bw[g + 3] = vw.w;
-            }
-            float m[P];
-            bool any = false;
-#pragma unroll
-            for (int p = 0; p < P; ++p) {
-                m[p] = -INFINITY;
-#pragma unroll
-                for (int b = 0; b < kGenBlock; ++b) m[p] = __builtin_fmaxf(m[p], general_filter<P>(p, gx, gy, gz, fx, fy, fz, a0, bx[b], by[b], bz[b], bw[b]));
-                any = any || m[p] >= o2[p];
-            }
-            if (__builtin_amdgcn_ballot_w64(any) == 0ull) continue;
-            // some lane has a candidate in this block (every bounce ray starts ON a sphere, so every wave gets here a few times): the
-            // spheres' exact-test operands are fetched together (one load latency, not one per sphere) and the per-sphere vote re-uses
-            // the constants the block was evaluated from
-            float4 sr[kGenBlock];
-#pragma unroll
-            for (int b = 0; b < kGenBlock; ++b) sr[b] = A.sph_r[c0 + s0 + b];
-#pragma unroll
-            for (int b = 0; b < kGenBlock; ++b) {
-                const int k = c0 + s0 + b;
-                uint32_t slots = 0u;
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    const bool cand = general_filter<P>(p, gx, gy, gz, fx, fy, fz, a0, bx[b], by[b], bz[b], bw[b]) >= o2[p];
-                    if (__builtin_amdgcn_ballot_w64(cand) != 0ull) slots |= 1u << p;
-                }
-#pragma unroll
-                for (int p = 0; p < P; ++p) {
-                    if (!((slots >> p) & 1u)) continue;  // wave-uniform: none of the 64 rays of this slot is a candidate of sphere k
-                    float t;
-                    const bool h = hit_general_exact(ox[p], oy[p], oz[p], ux[p], uy[p], uz[p], sr[b], t) && ((need >> p) & 1u);
-                    take_closest(h, t, k, best_t[p], best_i[p]);
-                }
-            }
-        }
-    }
-}
-
 // display.rs:98-100 + renderer.rs:43 — primary ray direction of pixel (x = column j, y = row i): exact reference arithmetic
 __device__ __forceinline__ void primary_dir(const RenderArgs& A, uint32_t x, uint32_t y, float& dx, float& dy, float& dz)
 {
@@ -968,15 +870,227 @@ __global__ __launch_bounds__(kWaves * 64) void shadow_mask_kernel(const RenderAr
     }
 }
 
+// Closest hit (renderer.rs:47-54) of the P bounce rays per lane of ONE WAVE over the whole scene -> best_t / best_i; `need` selects the
+// live rays.  No workgroup barrier: the wave works out of its own LDS (s_g: c'x | c'y | c'z | Kc planes of CAP entries, s_s: the
+// spheres themselves, s_i: their element indices, s_cl: open clusters).
+// Hierarchy, as for the shadow rays: the wave's records are neighbours in the spatial order, so its rays start inside a small ball
+// (centre oc, radius ro) and — the reference reflects about the normal at the OLD origin (renderer.rs:68), one normal per sphere on
+// the first bounce — point into a narrow cone (axis a, half-angle theta).  A ray of that bundle that the reference's test can accept
+// for sphere (c, r) passes, on its forward side, within  rho_e = sqrt(r^2 (1 + 1e-4) + E) + 5.66e-3 |q|  of c (general_filter's margins
+// read backwards: delta_ref >= 0 needs dist(c, line)^2 <= rho + 3.06e-5 |q|^2 + 116 u S2, E = 160 u S2max covers the last term), or
+// starts inside that radius.  With v = c - oc, D = |v| and T = rho_e + ro this needs  D <= T  or  angle(a, v) <= theta + asin(T / D),
+// i.e.  a.v >= cos(theta) sqrt(D^2 - T^2) - sin(theta) T.  Clusters of 16 spatially adjacent spheres are voted first with their
+// bounding sphere (A.gcl: centre, radius of the centres + largest member radius), then their members; what survives is listed in LDS
+// and walked with the 7-FMA filter, candidates are tested exactly out of LDS.  Every comparison is written so that a NaN or an
+// overflow keeps the sphere; bundles wider than 60 degrees keep everything (= the walk over the whole list).
+template <int P, int CAP>
+__device__ __forceinline__ void trace_bundle(const RenderArgs& A, float* s_g, float4* s_s, int* s_i, int* s_cl, int lane, uint32_t need,
+                                             const float (&ox)[P], const float (&oy)[P], const float (&oz)[P], const float (&ux)[P],
+                                             const float (&uy)[P], const float (&uz)[P], float (&best_t)[P], int (&best_i)[P])
+{
+    constexpr int B = kGenBlock;
+    static_assert(CAP % B == 0 && CAP >= 128 && B % 4 == 0, "list geometry");
+    float fx[P], fy[P], fz[P], gx[P], gy[P], gz[P], a0[P], o2[P], px[P], py[P], pz[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const bool on = (need >> p) & 1u;
+        // dead rays get an inert filter: direction 0 and an origin 1e18 away => h = -T << O2, never a candidate of a finite sphere
+        const float sx = on ? ux[p] * kGenDirScale : 0.0f, sy = on ? uy[p] * kGenDirScale : 0.0f, sz = on ? uz[p] * kGenDirScale : 0.0f;
+        px[p] = on ? ox[p] - A.ball[0] : 1.0e18f;
+        py[p] = on ? oy[p] - A.ball[1] : 1.0e18f;
+        pz[p] = on ? oz[p] - A.ball[2] : 1.0e18f;
+        a0[p] = __builtin_fmaf(sx, px[p], __builtin_fmaf(sy, py[p], sz * pz[p]));
+        o2[p] = __builtin_fmaf(px[p], px[p], __builtin_fmaf(py[p], py[p], pz[p] * pz[p])) * kGenO2Scale;
+        fx[p] = -sx; fy[p] = -sy; fz[p] = -sz;
+        gx[p] = -2.0f * px[p]; gy[p] = -2.0f * py[p]; gz[p] = -2.0f * pz[p];
+        best_i[p] = -1;
+        best_t[p] = 0.0f;
+    }
+    for (int a = 0; a < A.n_planes; ++a) {  // planes: no filter, exact test for every live ray
+        const int k = A.planes[a];
+        const float4 p0 = A.sph_r[k], n = A.pln[k];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            float t;
+            const bool h = hit_plane_exact(ox[p], oy[p], oz[p], ux[p], uy[p], uz[p], p0, n, t) && ((need >> p) & 1u);
+            take_closest(h, t, k, best_t[p], best_i[p]);
+        }
+    }
+    // ---- the bundle: origin ball and direction cone of the live rays with finite data (the others miss every exact test) ----
+    float sox = 0.0f, soy = 0.0f, soz = 0.0f, sdx = 0.0f, sdy = 0.0f, sdz = 0.0f, cnt = 0.0f;
+    uint32_t fin = 0u;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const bool f = ((need >> p) & 1u) && __builtin_isfinite(px[p]) && __builtin_isfinite(py[p]) && __builtin_isfinite(pz[p]) &&
+                       __builtin_isfinite(ux[p]) && __builtin_isfinite(uy[p]) && __builtin_isfinite(uz[p]);
+        if (f) {
+            fin |= 1u << p;
+            sox = sox + px[p]; soy = soy + py[p]; soz = soz + pz[p];
+            sdx = sdx + ux[p]; sdy = sdy + uy[p]; sdz = sdz + uz[p];
+            cnt = cnt + 1.0f;
+        }
+    }
+    cnt = wave_sum(cnt);
+    if (!(cnt > 0.0f)) return;  // (wave-uniform)
+    const float ocx = wave_sum(sox) / cnt, ocy = wave_sum(soy) / cnt, ocz = wave_sum(soz) / cnt;
+    float ax = wave_sum(sdx), ay = wave_sum(sdy), az = wave_sum(sdz);
+    const float an = sqrtf(ax * ax + ay * ay + az * az);
+    ax = ax / an; ay = ay / an; az = az / an;
+    float ro = 0.0f, cmin = INFINITY, smax = 0.0f;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        if (!((fin >> p) & 1u)) continue;
+        const float ex = px[p] - ocx, ey = py[p] - ocy, ez = pz[p] - ocz;
+        ro = __builtin_fmaxf(ro, sqrtf(ex * ex + ey * ey + ez * ez));
+        const float c = ax * ux[p] + ay * uy[p] + az * uz[p];
+        const float kx = ay * uz[p] - az * uy[p], ky = az * ux[p] - ax * uz[p], kz = ax * uy[p] - ay * ux[p];
+        cmin = __builtin_fminf(cmin, c);
+        smax = __builtin_fmaxf(smax, sqrtf(kx * kx + ky * ky + kz * kz));
+    }
+    ro = wave_max(ro) * (1.0f + 1.0e-5f) + 1.0e-30f;
+    cmin = wave_min(cmin);
+    smax = wave_max(smax);
+    const bool wide = !(an > 0.0f && an < INFINITY && cmin > 0.5f && cmin <= 2.0f && ro < INFINITY);
+    const float sinT = smax * (1.0f + 1.0e-6f) + 1.0e-6f;
+    const float cosT = sqrtf(__builtin_fmaxf(0.0f, 1.0f - sinT * sinT)) * (1.0f - 1.0e-6f);
+    const float on_ = sqrtf(ocx * ocx + ocy * ocy + ocz * ocz) + ro;  // >= |o'| of every ray of the bundle
+    const float E = 9.5367431640625e-06f * (on_ * on_ + A.ball[3] * 1.0021f);  // 160 u (|o'|^2 + |c'|^2): A.ball[3] = 0.998 Rs^2 >= ... |c'|^2 <= Rs^2
+    const float sqrtE = sqrtf(E);
+    // cull(v, D2, rho_e): true only if NO ray of the bundle can have an accepted hit on a sphere centred at oc + v with effective radius rho_e
+    auto cull = [&](float vx, float vy, float vz, float D2, float D, float rho_e) -> bool {
+        const float T = (rho_e + ro) * (1.0f + 1.0e-4f) + 1.0e-4f * D;
+        const float w1 = sqrtf(__builtin_fmaxf(0.0f, D2 * (1.0f - 1.0e-5f) - T * T));
+        const float dot = ax * vx + ay * vy + az * vz;
+        return !wide && D > T && dot < cosT * w1 - sinT * T - 1.0e-5f * D;
+    };
+    int count = 0;
+    float* const s_x = s_g;
+    float* const s_y = s_g + CAP;
+    float* const s_z = s_g + 2 * CAP;
+    float* const s_k = s_g + 3 * CAP;
+    auto walk = [&]() {
+        const int padded = (count + B - 1) / B * B;
+        if (count + lane < padded) {  // pad the last block with entries that never pass (Kc = +inf: h = -inf)
+            s_x[count + lane] = 0.0f;
+            s_y[count + lane] = 0.0f;
+            s_z[count + lane] = 0.0f;
+            s_k[count + lane] = INFINITY;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (int s0 = 0; s0 < padded; s0 += B) {
+            float bx[B], by[B], bz[B], bw[B];
+#pragma unroll
+            for (int g = 0; g < B; g += 4) {  // wave-uniform addresses: broadcast ds_read_b128, four spheres per read
+                const float4 vx = *reinterpret_cast<const float4*>(&s_x[s0 + g]);
+                const float4 vy = *reinterpret_cast<const float4*>(&s_y[s0 + g]);
+                const float4 vz = *reinterpret_cast<const float4*>(&s_z[s0 + g]);
+                const float4 vw = *reinterpret_cast<const float4*>(&s_k[s0 + g]);
+                bx[g] = vx.x; bx[g + 1] = vx.y; bx[g + 2] = vx.z; bx[g + 3] = vx.w;
+                by[g] = vy.x; by[g + 1] = vy.y; by[g + 2] = vy.z; by[g + 3] = vy.w;
+                bz[g] = vz.x; bz[g + 1] = vz.y; bz[g + 2] = vz.z; bz[g + 3] = vz.w;
+                bw[g] = vw.x; bw[g + 1] = vw.y; bw[g + 2] = vw.z; bw[g + 3] = vw.w;
+            }
+            float m[P];
+            bool any = false;
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                m[p] = -INFINITY;
+#pragma unroll
+                for (int b = 0; b < B; ++b) m[p] = __builtin_fmaxf(m[p], general_filter<P>(p, gx, gy, gz, fx, fy, fz, a0, bx[b], by[b], bz[b], bw[b]));
+                any = any || m[p] >= o2[p];
+            }
+            if (__builtin_amdgcn_ballot_w64(any) == 0ull) continue;
+            // some lane has a candidate in this block (every bounce ray starts ON a sphere): per-sphere vote from the registers the block
+            // was evaluated from, exact test out of LDS and only for the ray slots that hold a candidate
+#pragma unroll
+            for (int b = 0; b < B; ++b) {
+                uint32_t slots = 0u;
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const bool cand = general_filter<P>(p, gx, gy, gz, fx, fy, fz, a0, bx[b], by[b], bz[b], bw[b]) >= o2[p];
+                    if (__builtin_amdgcn_ballot_w64(cand) != 0ull) slots |= 1u << p;
+                }
+                if (slots == 0u) continue;
+                const float4 sr = s_s[s0 + b];
+                const int k = s_i[s0 + b];
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    if (!((slots >> p) & 1u)) continue;  // wave-uniform: none of the 64 rays of this slot is a candidate of sphere k
+                    float t;
+                    const bool h = hit_general_exact(ox[p], oy[p], oz[p], ux[p], uy[p], uz[p], sr, t) && ((need >> p) & 1u);
+                    take_closest(h, t, k, best_t[p], best_i[p]);
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        count = 0;
+    };
+    const int n_cl = A.n_pad / 16;
+    for (int cb = 0; cb < n_cl; cb += 256) {
+        // ---- cluster vote: four clusters per lane, their loads in flight together; open clusters -> s_cl ----
+        float4 cc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = cb + 64 * i + lane;
+            cc[i] = c < n_cl ? A.gcl[c] : make_float4(0.0f, 0.0f, 0.0f, -1.0f);
+        }
+        int n_open = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = cb + 64 * i + lane;
+            const float vx = cc[i].x - ocx, vy = cc[i].y - ocy, vz = cc[i].z - ocz;
+            const float D2 = vx * vx + vy * vy + vz * vz, D = sqrtf(D2);
+            const float rho_e = cc[i].w + sqrtE + 5.66e-3f * (D + cc[i].w + ro);  // w = radius of the centres + largest member radius (1 + 1e-4)
+            const bool open_ = c < n_cl && !(cc[i].w < 0.0f) && !cull(vx, vy, vz, D2, D, rho_e);  // w = -1: empty cluster
+            const uint64_t mask = __builtin_amdgcn_ballot_w64(open_);
+            if (open_) s_cl[n_open + (int)lanes_below(mask)] = c;
+            n_open += __builtin_popcountll(mask);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- member vote: four open clusters at a time, 16 lanes each ----
+        for (int base = 0; base < n_open; base += 4) {
+            const int ci = base + (lane >> 4);
+            const int j = (ci < n_open ? s_cl[ci] : 0) * 16 + (lane & 15);
+            const float4 g = A.gen_o[j];
+            const float4 sp = A.sph_o[j];
+            const float vx = g.x - ocx, vy = g.y - ocy, vz = g.z - ocz;
+            const float D2 = vx * vx + vy * vy + vz * vz, D = sqrtf(D2);
+            const float rho_e = sqrtf(sp.w * sp.w * (1.0f + 1.0e-4f) + E) + 5.66e-3f * (D + ro);
+            // Kc = +inf: padding / plane, never a candidate; Kc = -inf: a sphere outside the filter's argument, always a candidate
+            const bool keep = ci < n_open && g.w != INFINITY && (g.w == -INFINITY || !cull(vx, vy, vz, D2, D, rho_e));
+            const uint64_t km = __builtin_amdgcn_ballot_w64(keep);
+            if (km == 0ull) continue;
+            if (keep) {
+                const int at = count + (int)lanes_below(km);
+                s_x[at] = g.x;
+                s_y[at] = g.y;
+                s_z[at] = g.z;
+                s_k[at] = g.w;
+                s_s[at] = sp;
+                s_i[at] = A.order[j];
+            }
+            count += __builtin_popcountll(km);
+            if (count > CAP - 64) walk();
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (count > 0) walk();
+}
+
 // One iteration (A.iter) of renderer.rs:46-73 for the live records: hit point, lights in list order (occlusion bits from
 // shadow_mask_kernel when RT_SHADOWS), (x) reflectiveness; then either the final store (last iteration) or the bounce (normal at
-// the OLD origin, renderer.rs:68; reflect, object/mod.rs:71-73; no epsilon) and the closest hit of the bounce ray (trace_general).
+// the OLD origin, renderer.rs:68; reflect, object/mod.rs:71-73; no epsilon) and the closest hit of the bounce ray (trace_bundle).
 // A ray that misses keeps its colour for good (renderer.rs:47-56: prev_info stays untouched), so its pixel is stored at once and the
-// record is marked dead (rec_idx = -1).  A wave owns 64*P consecutive records (neighbouring pixels: wave votes stay effective).
-template <int P>
-__device__ __forceinline__ void shade_records(const RenderArgs& A, float* s_buf, int tid, uint32_t count, uint32_t wave_first)
+// record is marked dead (rec_idx = -1).  A wave owns 64*P consecutive entries of the record list — of the spatially sorted list of
+// live records (A.rec_perm) when the iteration was sorted (A.sorted: always when it traces bounces or casts shadow rays), so that its
+// bounce rays form the narrow bundle trace_bundle feeds on; of the emission order otherwise (neighbouring pixels).
+template <int P, int CAP>
+__device__ __forceinline__ void shade_records(const RenderArgs& A, float* s_g, float4* s_s, int* s_i, int* s_cl, int lane, uint32_t count, uint32_t wave_first)
 {
-    const int lane = tid & 63;
     const bool shadows = (A.flags & RT_SHADOWS) != 0u;
     const bool last = A.iter + 1u >= A.depth;  // renderer.rs:67 (i < limit)
     const size_t cap = A.rec_cap;
@@ -987,9 +1101,10 @@ __device__ __forceinline__ void shade_records(const RenderArgs& A, float* s_buf,
     uint32_t alive = 0u;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        const uint32_t r = wave_first + p * 64 + lane;
+        const uint32_t e = wave_first + p * 64 + lane;
+        bool ok = e < count;
+        const uint32_t r = A.sorted ? (ok ? A.rec_perm[e] : 0u) : e;
         rec[p] = r;
-        bool ok = r < count;
         best_i[p] = ok ? A.rec_idx[r] : -1;
         ok = ok && best_i[p] >= 0;
         pix[p] = ok ? A.rec_pix[r] : 0u;
@@ -1066,7 +1181,7 @@ __device__ __forceinline__ void shade_records(const RenderArgs& A, float* s_buf,
         dx[p] = ex; dy[p] = ey; dz[p] = ez;
         ox[p] = hx[p]; oy[p] = hy[p]; oz[p] = hz[p];  // renderer.rs:70
     }
-    trace_general<P>(A, s_buf, tid, alive, ox, oy, oz, dx, dy, dz, best_t, best_i);  // uniform over the workgroup (barriers inside)
+    trace_bundle<P, CAP>(A, s_g, s_s, s_i, s_cl, lane, alive, ox, oy, oz, dx, dy, dz, best_t, best_i);
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         if (!((alive >> p) & 1u)) continue;
@@ -1083,18 +1198,21 @@ __device__ __forceinline__ void shade_records(const RenderArgs& A, float* s_buf,
     }
 }
 
-// A workgroup owns 4 * 64 * P consecutive records and its waves walk the LDS chunks of the list together (barriers).  (A persistent
-// grid whose waves pull 64 * P-record units from a queue was measured and lost, 0.66 against 0.31 ms on C3 depth 2: returning atomics
-// on one address complete at only ~40-80 M/s chip-wide, and 7168 resident waves all fetch at once; profiles/r03_tuning.md.)
-template <int P>
+// The four waves of a workgroup are independent (no barrier): each owns 64 * P entries and its own slice of LDS.  (A persistent grid
+// whose waves pull their units from a queue was measured and lost, 0.66 against 0.31 ms on C3 depth 2 when the trace still walked the
+// whole list: returning atomics on one address complete at only ~40-80 M/s chip-wide; profiles/r03_tuning.md.)
+template <int P, int CAP>
 __global__ __launch_bounds__(kWaves * 64) void shade_iter_kernel(const RenderArgs A)
 {
-    __shared__ __attribute__((aligned(16))) float s_buf[4 * kChunk];
-    const int tid = threadIdx.x;
-    const uint32_t count = *A.rec_count;
-    const uint32_t wg_first = blockIdx.x * (kWaves * 64 * P);
-    if (wg_first >= count) return;  // whole workgroup: no barrier has been executed yet
-    shade_records<P>(A, s_buf, tid, count, wg_first + (uint32_t)(tid >> 6) * (64 * P));
+    __shared__ __attribute__((aligned(16))) float s_g[kWaves][4 * CAP];
+    __shared__ float4 s_s[kWaves][CAP];
+    __shared__ int s_i[kWaves][CAP];
+    __shared__ int s_cl[kWaves][256];
+    const int wave = threadIdx.x >> 6;
+    const uint32_t count = A.sorted ? A.rec_count[1] : A.rec_count[0];
+    const uint32_t wave_first = (blockIdx.x * kWaves + (uint32_t)wave) * (64 * P);
+    if (wave_first >= count) return;
+    shade_records<P, CAP>(A, s_g[wave], s_s[wave], s_i[wave], s_cl[wave], threadIdx.x & 63, count, wave_first);
 }
 
 // Zeroes scratch words with a KERNEL, not hipMemsetAsync: `planes` planes of `n` words, `stride` words apart, starting at p; plus up to
@@ -1136,6 +1254,10 @@ constexpr int kB = RT_B;       // spheres per wave vote in the primary loop (swe
 #define RT_SHADE_P 2
 #endif
 constexpr int kShadeP = RT_SHADE_P;  // records per lane in shade_iter_kernel
+#ifndef RT_SHADE_CAP
+#define RT_SHADE_CAP 128
+#endif
+constexpr int kShadeCap = RT_SHADE_CAP;  // entries of the per-wave sphere list of trace_bundle (36 B each in LDS)
 #ifndef RT_MASK_P
 #define RT_MASK_P 4
 #endif
@@ -1270,7 +1392,8 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream, PhaseEvents
     const bool shadows = (args.flags & RT_SHADOWS) != 0u && args.n_lights > 0;
     const uint64_t npix = (uint64_t)(args.y1 - args.y0) * args.w;
     if (!args.rec_count || !args.rec_pix || !args.rec_idx || !args.rec_t || args.rec_cap < npix) return hipErrorInvalidValue;
-    if ((args.depth > 1u && !args.rec_state) || (shadows && (!args.rec_occ || !args.rec_perm || !args.rec_hit || !args.sort_bins))) return hipErrorInvalidValue;
+    if ((args.depth > 1u && !args.rec_state) || (shadows && !args.rec_occ)) return hipErrorInvalidValue;
+    if ((shadows || args.depth > 1u) && (!args.rec_perm || !args.rec_hit || !args.sort_bins)) return hipErrorInvalidValue;
     hipError_t e = clear_words(nullptr, 0, 0, 0, args.rec_count, 1, stream);
     if (e != hipSuccess) return e;
     if (phases && (e = hipEventRecord(phases->ev[0], stream)) != hipSuccess) return e;
@@ -1286,16 +1409,20 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream, PhaseEvents
     const uint32_t occ_words = ((uint32_t)args.n_lights + 31u) / 32u;
     for (uint32_t it = 0; it < args.depth; ++it) {  // renderer.rs:46
         a.iter = it;
-        if (shadows) {
-            // only the words of this band's records (at most npix per plane), not the whole capacity of the scratch; and the sort bins
-            if (kMaskLC != 32 && (e = clear_words(a.rec_occ, (size_t)npix, a.rec_cap, occ_words, nullptr, 0, stream)) != hipSuccess) return e;
+        const bool tracing = it + 1u < args.depth;  // this iteration ends with a bounce
+        a.sorted = (shadows || tracing) ? 1u : 0u;
+        if (a.sorted) {
+            // spatial sort of the live records (rec_idx of this iteration) -> rec_perm, their hit points -> rec_hit, live count -> rec_count[1]
             if ((e = clear_words(a.sort_bins, (size_t)a.n + 1, 0, 1, nullptr, 0, stream)) != hipSuccess) return e;
-            // spatial sort of the live records (rec_idx of this iteration) -> rec_perm, live count -> rec_count[1]
             const uint32_t sort_wgs = (uint32_t)(npix + 255) / 256 < 2048u ? (uint32_t)(npix + 255) / 256 : 2048u;
             hipLaunchKernelGGL((sort_records_kernel<false>), dim3(sort_wgs), dim3(256), 0, stream, a);
             hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(256), 0, stream, a);
             hipLaunchKernelGGL((sort_records_kernel<true>), dim3(sort_wgs), dim3(256), 0, stream, a);
             if ((e = hipGetLastError()) != hipSuccess) return e;
+        }
+        if (shadows) {
+            // only the words of this band's records (at most npix per plane), not the whole capacity of the scratch
+            if (kMaskLC != 32 && (e = clear_words(a.rec_occ, (size_t)npix, a.rec_cap, occ_words, nullptr, 0, stream)) != hipSuccess) return e;
             const uint64_t worst_tiles = (npix + 64 * kMaskP - 1) / (64 * kMaskP) * (uint64_t)(((uint32_t)args.n_lights + kMaskLC - 1) / kMaskLC);
             if (worst_tiles >= (1ull << 32)) return hipErrorInvalidValue;  // the tile queue counts in 32 bits
             const uint64_t worst_wgs = (worst_tiles + kWaves - 1) / kWaves;
@@ -1305,7 +1432,7 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream, PhaseEvents
         }
         const bool timed = phases && it < kPhaseIters;
         if (timed && (e = hipEventRecord(phases->ev[2 + 2 * it], stream)) != hipSuccess) return e;
-        hipLaunchKernelGGL((shade_iter_kernel<kShadeP>), dim3(shade_wgs), dim3(kWaves * 64), kShadeLdsPad, stream, a);
+        hipLaunchKernelGGL((shade_iter_kernel<kShadeP, kShadeCap>), dim3(shade_wgs), dim3(kWaves * 64), kShadeLdsPad, stream, a);
         if ((e = hipGetLastError()) != hipSuccess) return e;
         if (timed) {
             if ((e = hipEventRecord(phases->ev[3 + 2 * it], stream)) != hipSuccess) return e;
@@ -1315,11 +1442,13 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream, PhaseEvents
     return hipSuccess;
 }
 
-void render_scratch_layout(const RenderArgs& args, bool& need_state, uint32_t& occ_words, uint32_t& bin_words)
+void render_scratch_layout(const RenderArgs& args, bool& need_state, uint32_t& occ_words, uint32_t& sort_planes, uint32_t& bin_words)
 {
     need_state = args.depth > 1u;
     occ_words = ((args.flags & RT_SHADOWS) != 0u && args.n_lights > 0) ? ((uint32_t)args.n_lights + 31u) / 32u : 0u;
-    bin_words = occ_words ? ((uint32_t)args.n + 1u + 3u) / 4u * 4u : 0u;
+    const bool sorted = need_state || occ_words > 0u;  // iterations that trace bounces or cast shadow rays work on spatially sorted records
+    sort_planes = sorted ? 4u : 0u;                    // rec_perm + three planes of hit points
+    bin_words = sorted ? ((uint32_t)args.n + 1u + 3u) / 4u * 4u : 0u;
 }
 
 const char* render_kernel_name(const RenderArgs& args)

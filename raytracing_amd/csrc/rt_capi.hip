@@ -43,7 +43,7 @@ struct rt_ctx {
     int32_t n = 0, n_pad = 0, n_always = 0, n_lights = 0;
     void* d_scene = nullptr;  // one allocation, sub-arrays below point into it
     size_t scene_bytes = 0;
-    const float4 *d_filt = nullptr, *d_sph = nullptr, *d_sph_r = nullptr, *d_gen = nullptr, *d_refl = nullptr, *d_lpos = nullptr, *d_lcol = nullptr;
+    const float4 *d_filt = nullptr, *d_sph = nullptr, *d_sph_r = nullptr, *d_gen_o = nullptr, *d_gcl = nullptr, *d_refl = nullptr, *d_lpos = nullptr, *d_lcol = nullptr;
     const int32_t* d_always = nullptr;
     const float4 *d_lfilt = nullptr, *d_lclA = nullptr, *d_lclB = nullptr, *d_sph_o = nullptr;
     const int32_t *d_order = nullptr, *d_rank = nullptr;
@@ -439,12 +439,13 @@ int32_t rt_scene_upload(rt_ctx* c, const rt_objects* o, const rt_lights* l)
     const size_t off_order = off_clB + (nl ? nl : 1) * ncl * 16;
     const size_t off_rank = off_order + np * 4;
     const size_t off_sph_o = off_rank + np * 4;
-    const size_t total = off_sph_o + np * 16;
+    const size_t off_gcl = off_sph_o + np * 16;
+    const size_t total = off_gcl + ncl * 16;
     std::vector<unsigned char> host(total, 0);
     std::memcpy(host.data() + off_filt, ps.filt.data(), np * 16);
     std::memcpy(host.data() + off_sph, ps.sph.data(), np * 16);
     std::memcpy(host.data() + off_sph_r, ps.sph_r.data(), np * 16);
-    std::memcpy(host.data() + off_gen, ps.gen.data(), np * 16);
+    std::memcpy(host.data() + off_gen, ps.gen_o.data(), np * 16);
     std::memcpy(host.data() + off_refl, ps.refl.data(), np * 16);
     if (nl) std::memcpy(host.data() + off_lpos, ps.lpos.data(), nl * 16);
     if (nl) std::memcpy(host.data() + off_lcol, ps.lcol.data(), nl * 16);
@@ -459,6 +460,7 @@ int32_t rt_scene_upload(rt_ctx* c, const rt_objects* o, const rt_lights* l)
     std::memcpy(host.data() + off_order, ps.order.data(), np * 4);
     std::memcpy(host.data() + off_rank, ps.rank.data(), np * 4);
     std::memcpy(host.data() + off_sph_o, ps.sph_o.data(), np * 16);
+    std::memcpy(host.data() + off_gcl, ps.gcl.data(), ncl * 16);
 
     RT_HIP(c, hipDeviceSynchronize());  // no render may still read the old scene (launches may sit on caller streams too)
     if (total > c->scene_bytes) {
@@ -475,7 +477,7 @@ int32_t rt_scene_upload(rt_ctx* c, const rt_objects* o, const rt_lights* l)
     c->d_filt = reinterpret_cast<const float4*>(base + off_filt);
     c->d_sph = reinterpret_cast<const float4*>(base + off_sph);
     c->d_sph_r = reinterpret_cast<const float4*>(base + off_sph_r);
-    c->d_gen = reinterpret_cast<const float4*>(base + off_gen);
+    c->d_gen_o = reinterpret_cast<const float4*>(base + off_gen);
     c->d_refl = reinterpret_cast<const float4*>(base + off_refl);
     c->d_lpos = reinterpret_cast<const float4*>(base + off_lpos);
     c->d_lcol = reinterpret_cast<const float4*>(base + off_lcol);
@@ -490,6 +492,7 @@ int32_t rt_scene_upload(rt_ctx* c, const rt_objects* o, const rt_lights* l)
     c->d_order = reinterpret_cast<const int32_t*>(base + off_order);
     c->d_rank = reinterpret_cast<const int32_t*>(base + off_rank);
     c->d_sph_o = reinterpret_cast<const float4*>(base + off_sph_o);
+    c->d_gcl = reinterpret_cast<const float4*>(base + off_gcl);
     c->n_planes = (int32_t)npl;
     std::memcpy(c->ball, ps.ball, sizeof(c->ball));
     c->n = ps.n;
@@ -576,18 +579,18 @@ static int32_t enqueue_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h
     std::memcpy(a.m, m, sizeof(a.m));
     a.w = w; a.h = h; a.y0 = y0; a.y1 = y1; a.depth = depth; a.flags = flags;
     a.n = c->n; a.n_pad = c->n_pad; a.n_always = c->n_always; a.n_lights = c->n_lights;
-    a.filt = c->d_filt; a.sph = c->d_sph; a.sph_r = c->d_sph_r; a.gen = c->d_gen; a.refl = c->d_refl; a.always = c->d_always; a.lpos = c->d_lpos; a.lcol = c->d_lcol; a.lfilt = c->d_lfilt; a.lclA = c->d_lclA; a.lclB = c->d_lclB; a.order = c->d_order; a.sph_o = c->d_sph_o; a.rank = c->d_rank; a.lalways = c->d_lalways; a.lalways_off = c->d_lalways_off; a.pln = c->d_pln; a.planes = c->d_planes; a.n_planes = c->n_planes; std::memcpy(a.ball, c->ball, sizeof(a.ball));
+    a.filt = c->d_filt; a.sph = c->d_sph; a.sph_r = c->d_sph_r; a.gen_o = c->d_gen_o; a.gcl = c->d_gcl; a.refl = c->d_refl; a.always = c->d_always; a.lpos = c->d_lpos; a.lcol = c->d_lcol; a.lfilt = c->d_lfilt; a.lclA = c->d_lclA; a.lclB = c->d_lclB; a.order = c->d_order; a.sph_o = c->d_sph_o; a.rank = c->d_rank; a.lalways = c->d_lalways; a.lalways_off = c->d_lalways_off; a.pln = c->d_pln; a.planes = c->d_planes; a.n_planes = c->n_planes; std::memcpy(a.ball, c->ball, sizeof(a.ball));
     a.out = static_cast<uint8_t*>(d_out);
     a.hit_idx = static_cast<int32_t*>(d_hit_idx);
     a.rec_count = nullptr; a.rec_pix = nullptr; a.rec_idx = nullptr; a.rec_t = nullptr;
     a.strips = a.tiles4 = a.tiles2 = a.tiles1 = a.rows4 = a.rows2 = 0;
-    a.rec_cap = 0; a.iter = 0; a.rec_state = nullptr; a.rec_occ = nullptr; a.rec_perm = nullptr; a.rec_hit = nullptr; a.sort_bins = nullptr;
+    a.rec_cap = 0; a.iter = 0; a.sorted = 0; a.rec_state = nullptr; a.rec_occ = nullptr; a.rec_perm = nullptr; a.rec_hit = nullptr; a.sort_bins = nullptr;
     const bool general = render_needs_records(a);
     const size_t npix = (size_t)(y1 - y0) * w;
     bool need_state = false;
-    uint32_t occ_words = 0, bin_words = 0;
-    render_scratch_layout(a, need_state, occ_words, bin_words);
-    const size_t planes = 3 + (need_state ? 9 : 0) + occ_words + (occ_words ? 4 : 0);
+    uint32_t occ_words = 0, sort_planes = 0, bin_words = 0;
+    render_scratch_layout(a, need_state, occ_words, sort_planes, bin_words);
+    const size_t planes = 3 + (need_state ? 9 : 0) + occ_words + sort_planes;
 
     uint32_t slot = 0;
     char* rec_base = nullptr;
@@ -636,8 +639,8 @@ static int32_t enqueue_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h
         a.rec_idx = reinterpret_cast<int32_t*>(rec_base + 16 + plane);
         a.rec_t = reinterpret_cast<float*>(rec_base + 16 + 2 * plane);
         if (need_state) a.rec_state = reinterpret_cast<float*>(rec_base + 16 + 3 * plane);
-        if (occ_words) {
-            a.rec_occ = reinterpret_cast<uint32_t*>(rec_base + 16 + (3 + (need_state ? 9 : 0)) * plane);
+        if (occ_words) a.rec_occ = reinterpret_cast<uint32_t*>(rec_base + 16 + (3 + (need_state ? 9 : 0)) * plane);
+        if (sort_planes) {
             a.rec_perm = reinterpret_cast<uint32_t*>(rec_base + 16 + (3 + (need_state ? 9 : 0) + occ_words) * plane);
             a.rec_hit = reinterpret_cast<float*>(rec_base + 16 + (3 + (need_state ? 9 : 0) + occ_words + 1) * plane);
             // the bins sit behind ALL planes of the layout in use (context scratch: behind its allocated planes)

@@ -344,6 +344,45 @@ std::string prepare_scene(const rt_objects* o, const rt_lights* l, PreparedScene
     out.sph_o.assign(out.n_pad, f4{0, 0, 0, NAN});
     for (int32_t j = 0; j < out.n_pad; ++j)
         if (out.order[j] >= 0) out.sph_o[j] = out.sph_r[out.order[j]];
+    // bounce trace (render_kernels.hip: trace_bundle): the general-origin filter constants in spatial order and, per cluster of 16
+    // consecutive positions, a bounding sphere of the members (centres c' as the kernel sees them, in f32)
+    out.gen_o.assign(out.n_pad, f4{0, 0, 0, inf});
+    for (int32_t j = 0; j < out.n_pad; ++j)
+        if (out.order[j] >= 0) out.gen_o[j] = out.gen[out.order[j]];
+    const int32_t ncl = out.n_pad / kShadowCluster;
+    out.gcl.assign(ncl, f4{0, 0, 0, -1.0f});
+    for (int32_t cl = 0; cl < ncl; ++cl) {
+        double sx = 0, sy = 0, sz = 0;
+        int members = 0;
+        bool open = false;
+        for (int32_t jj = 0; jj < kShadowCluster; ++jj) {
+            const int32_t j = cl * kShadowCluster + jj;
+            const f4 g = out.gen_o[j];
+            if (g.w == inf) continue;  // padding / plane: never a candidate
+            const float r = out.sph_o[j].w;
+            if (!(std::isfinite(g.x) && std::isfinite(g.y) && std::isfinite(g.z) && std::isfinite(g.w) && std::isfinite(r))) {
+                open = true;  // non-finite data, or Kc = -inf (a sphere outside the filter's argument): the cluster is never skipped
+                continue;
+            }
+            sx += g.x; sy += g.y; sz += g.z;
+            ++members;
+        }
+        if (!members && !open) continue;
+        f4 c = f4{0, 0, 0, inf};
+        if (!open) {
+            c.x = (float)(sx / members); c.y = (float)(sy / members); c.z = (float)(sz / members);
+            double R = 0;
+            for (int32_t jj = 0; jj < kShadowCluster; ++jj) {
+                const int32_t j = cl * kShadowCluster + jj;
+                const f4 g = out.gen_o[j];
+                if (g.w == inf) continue;
+                const double ex = (double)g.x - c.x, ey = (double)g.y - c.y, ez = (double)g.z - c.z;
+                R = std::fmax(R, std::sqrt(ex * ex + ey * ey + ez * ez) + std::fabs((double)out.sph_o[j].w) * (1.0 + 1e-4));
+            }
+            c.w = std::nextafter((float)(R * (1.0 + 1e-6)), INFINITY);
+        }
+        out.gcl[cl] = c;
+    }
     prepare_light_filters(o, l, out);
     return std::string();
 }

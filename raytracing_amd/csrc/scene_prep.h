@@ -42,6 +42,9 @@ struct PreparedScene {
     // 3-FMA filter applies with sphere centres relative to lp and an inflated radius (scene_prep.cpp: prepare_light_filters)
     std::vector<int32_t> order;        // n_pad: element at spatial position j (Morton order of the sphere centres; planes last), -1 = padding
     std::vector<f4> sph_o;             // n_pad: sph_r in spatial order (the exact-test operands of shadow candidates)
+    std::vector<f4> gen_o;             // n_pad: gen in spatial order (what the bounce trace lists and walks)
+    std::vector<f4> gcl;               // n_pad / 16: per cluster of 16 consecutive positions (centre c' = c - ball centre, radius of the centres +
+                                       // largest member radius (1 + 1e-4), rounded up; +inf = a member outside the argument; -1 = no member)
     std::vector<int32_t> rank;         // n_pad: spatial position of element i (the sort key of the hit records)
     std::vector<f4> lfilt;             // n_lights * n_pad, in SPATIAL order: (c''x, c''y, c''z, P2 of the member test); all zero = no entry
     std::vector<f4> lclA, lclB;        // n_lights * n_pad / 16: per cluster of 16 consecutive entries (axis x, y, z, dmin), (cos, sin of the half-angle, 0, 0)

@@ -62,8 +62,8 @@ def test_noalloc_limits_and_whole_4k_primary(oracle):
         with pytest.raises(capi.RtError) as e:
             ctx.render_rows_device_noalloc(m, w, h, 0, h, 2, 0, img.data_ptr(), 0, st.cuda_stream)
         assert e.value.code == capi.RT_ERR_TOO_LARGE
-        # 12 planes (depth 2) x 4 B per pixel: 699050 pixels fit, i.e. 182 rows of 3840 pixels; 183 do not
-        limit_rows = (capi.RT_NOALLOC_SCRATCH_BYTES - 272) // (12 * 4 * w)
+        # 16 planes (depth 2: 3 + 9 of ray state + 4 of the record sort) x 4 B per pixel + the sort bins: 136 rows of 3840 pixels fit, 137 do not
+        limit_rows = (capi.RT_NOALLOC_SCRATCH_BYTES - 272 - 4 * (objs.n + 4)) // (16 * 4 * w)
         with pytest.raises(capi.RtError):
             ctx.render_rows_device_noalloc(m, w, h, 0, limit_rows + 1, 2, 0, img.data_ptr(), 0, st.cuda_stream)
         ctx.render_rows_device_noalloc(m, w, h, 0, limit_rows, 2, 0, img.data_ptr(), 0, st.cuda_stream)
