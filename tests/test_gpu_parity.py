@@ -440,6 +440,52 @@ def test_shadow_hierarchy_fuzz(gpu_ctx, oracle):
     print(f"shadow fuzz: {case + 1} scenes, {nrec} hit records")
 
 
+def test_bounce_hierarchy_fuzz(gpu_ctx, oracle):
+    """depth 2-4 on scenes built to stress trace_bundle (origin ball + direction cone per wave, cluster / member votes, per-wave list):
+    dense and clustered clouds with tens of thousands of bounce rays, overlapping spheres (bounce origins inside other spheres: the
+    Less branch), an enclosing sphere (every ray hits from inside, bundles wider than any cone), specks and huge spheres, planes (hit
+    points far outside the scene ball), wild scales, general camera matrices.  Byte-equal to the oracle.  RT_BOUNCE_FUZZ_CASES / _SEED widen it."""
+    rng = np.random.default_rng(int(os.environ.get("RT_BOUNCE_FUZZ_SEED", "47")))
+    f = np.float32
+    nrec = 0
+    for case in range(int(os.environ.get("RT_BOUNCE_FUZZ_CASES", "24"))):
+        w, h = int(rng.integers(160, 400)), int(rng.integers(100, 240))
+        n = int(rng.choice([3, 40, 200, 700, 1300, 2100]))
+        spread = f(rng.choice([3.0, 10.0, 40.0]) if case % 8 != 7 else rng.choice([1e-2, 2e3]))
+        k = int(rng.integers(1, 5))
+        cc = rng.standard_normal((k, 3)) * spread * np.array([1.0, 0.6, 0.5]) + np.array([0, 0, -2.0 * spread])
+        c = (cc[rng.integers(0, k, n)] + rng.standard_normal((n, 3)) * spread * rng.choice([0.15, 0.4, 0.9])).astype(f)
+        rad = (rng.random(n) ** 3 * spread * rng.choice([0.1, 0.3]) + 1e-3 * spread).astype(f)
+        if case % 4 == 2:
+            c[0] = (0, 0, 0); rad[0] = f(spread * 6)  # the camera and the whole cloud inside one sphere
+        if case % 4 == 3:
+            rad[: n // 3] *= f(4.0)  # heavy overlap
+        refl = (rng.random((3, n)) * 1.1).astype(f)
+        objs = capi.FlatObjects(c[:, 0], c[:, 1], c[:, 2], rad, refl[0], refl[1], refl[2])
+        if case % 5 == 1:
+            objs = _with_planes(objs, [((0.0, float(-spread), 0.0), (0.0, 1.0, 0.03), (0.6, 0.6, 0.6)), ((0.0, 0.0, float(-5 * spread)), (0.1, 0.0, 1.0), (0.4, 0.7, 0.9))])
+        nl = int(rng.integers(1, 5))
+        lp = (rng.standard_normal((nl, 3)) * spread * 1.5 + np.array([0, 0, -1.0 * spread])).astype(f)
+        lc = rng.random((3, nl)).astype(f)
+        lights = capi.FlatLights(lp[:, 0], lp[:, 1], lp[:, 2], lc[0], lc[1], lc[2], (rng.random(nl) * spread * spread * 2).astype(f),
+                                 kind=(rng.random(nl) < 0.2).astype(np.uint8))
+        if case % 3 == 0:
+            m = (rng.standard_normal(16) * 0.6).astype(f)
+            m[10] -= f(1.5)
+        else:
+            m = oracle.camera_transform(f(rng.uniform(0.5, 1.6)), f(0.01), f(1000.0), f(w) / f(h))
+        depth = 2 + case % 3
+        flags = (capi.RT_SHADOWS if case % 2 else 0) | (capi.RT_OUT_RGB8 if case % 9 == 0 else 0)
+        gpu_ctx.scene_upload(objs, lights)
+        gpu, hit = gpu_ctx.render_rows(m, w, h, 0, h, depth, flags, want_hit_idx=True)
+        ref, ref_hit = oracle.render(objs, lights, m, w, h, depth=depth, flags=flags & 1, channels=3 if flags & 2 else 4, want_hit_idx=True)
+        _assert_same(gpu, ref, f"bounce fuzz case {case}: {w}x{h} n={objs.n} depth={depth} flags={flags}")
+        assert np.array_equal(hit, ref_hit)
+        nrec += int((hit >= 0).sum())
+    assert nrec > 150000
+    print(f"bounce fuzz: {case + 1} scenes, {nrec} hit records")
+
+
 def test_wavefront_many_lights_depth_and_bands(gpu_ctx, oracle):
     """General-ray kernels (shadow_mask_kernel + shade_iter_kernel): more than 32 lights (two occlusion words per record) with ambient
     lights in between, depth 3 with shadows, row bands, and the scratch planes reused across calls with different needs."""
