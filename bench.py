@@ -24,7 +24,7 @@ if ROOT not in sys.path:
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 FLOPS_PER_TEST = 6             # the hot loop executes three v_fma_f32 per (pixel, sphere) pair (render_kernels.h)
 FLOPS_PER_SHADOW_TEST = 6      # shadow_mask_kernel: the same 3-FMA filter per (shadow ray, sphere) with per-light constants
-FLOPS_PER_BOUNCE_TEST = 14     # trace_general: 7 FMAs per (bounce ray, sphere) (round 2: 10 operations, 16 flops)
+FLOPS_PER_BOUNCE_TEST = 14     # trace_bundle's filter: 7 FMAs per (bounce ray, sphere) it tests (round 2 walked the whole list with 10 operations, 16 flops)
 
 
 def main():
@@ -347,11 +347,23 @@ def main():
                              "(%d per (shadow ray,sphere) filter test x %d hit records x %d point lights x %d spheres x %d iteration(s))" %
                              (sh_flops, sh_flops / bound, FLOPS_PER_SHADOW_TEST, n_hits, n_point, objs.n, args.depth)) if sh_flops else
                             "executed flops unknown (%s); no-early-out bound %.4g" % (pnote, bound)))
+        bounce_info = None
         if general and args.depth > 1:
-            bo_tests = n_hits * objs.n * (args.depth - 1)
-            kernels.append(("shade_iter_kernel (shading + trace_general)", bo_tests, FLOPS_PER_BOUNCE_TEST, phase_ms[2],
-                            "%d per (bounce ray,sphere) filter test x %d hit records x %d spheres x %d bounce(s): an upper bound, rays that miss die" %
-                            (FLOPS_PER_BOUNCE_TEST, n_hits, objs.n, args.depth - 1)))
+            # shade_iter_kernel: shading + the bounce trace, whose hierarchy (trace_bundle) tests only the spheres a wave's bundle of rays
+            # can reach: executed flops = the counter-derived figure of the committed PMC pass of this command (None without one), beside
+            # the bound of walking the whole list with the 7-FMA filter for every bounce ray
+            bound = FLOPS_PER_BOUNCE_TEST * n_hits * objs.n * (args.depth - 1)
+            pv, pnote = pmc_summary(args.config, args.depth, args.shadows, "shade_iter_kernel")
+            bo_flops = pv.get("flops") if pv else None
+            if bo_flops:
+                bo_flops *= args.depth  # the summary averages the launches of one frame: one per iteration of renderer.rs:46
+            bounce_info = {"whole_list_bound_flops": bound, "executed_flops": bo_flops, "executed_over_bound": (bo_flops / bound) if bo_flops else None,
+                           "lane_utilisation": pv.get("lane_utilisation") if pv else None,
+                           "source": ("counter-derived flops " + pnote + ", x %d launches per frame" % args.depth) if bo_flops else pnote}
+            kernels.append(("shade_iter_kernel (shading + trace_bundle)", 1, bo_flops or 0.0, phase_ms[2],
+                            ("counter-derived: %.4g flops per frame, %.3f of the whole-list bound (%d per (bounce ray,sphere) filter test x %d hit records x %d spheres x %d bounce(s))" %
+                             (bo_flops, bo_flops / bound, FLOPS_PER_BOUNCE_TEST, n_hits, objs.n, args.depth - 1)) if bo_flops else
+                            "executed flops unknown (%s); whole-list bound %.4g" % (pnote, bound)))
         kernels.sort(key=lambda k_: -k_[3])
         dom = kernels[0]
         wall_based = slots > 1
@@ -397,7 +409,7 @@ def main():
                                    "kernels": [{"kernel": k_[0], "ms": k_[3], "TFLOP/s": (k_[1] * k_[2] / (k_[3] * 1e-3) / 1e12) if k_[3] > 0 else None,
                                                 "frac": (k_[1] * k_[2] / (k_[3] * 1e-3) / 1e12 / PEAK_FP32_VALU_TFLOPS) if k_[3] > 0 else None,
                                                 "flops_counted": k_[4]} for k_ in kernels],
-                                   "shadow_any_hit": shadow_info,
+                                   "shadow_any_hit": shadow_info, "bounce_closest_hit": bounce_info,
                                    "rays_per_step": w * h + (n_hits * n_point * args.depth if args.shadows else 0) + n_hits * (args.depth - 1),
                                    "note": "value counts primary rays only; rays_per_step adds the shadow and bounce rays (upper bounds: later iterations hold fewer live records)"}
         out["roofline"]["traffic"], out["roofline"]["traffic_note"] = pmc_traffic(args.config, args.depth, args.shadows, dom[0])

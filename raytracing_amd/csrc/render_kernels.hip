@@ -168,7 +168,7 @@ __device__ __forceinline__ void shade(const RenderArgs& A, bool active, int k, f
 constexpr float kGenDirScale = 1.0f + 1.52587890625e-05f;  // 1 + 2^-16
 constexpr float kGenO2Scale = 1.0f - 3.814697265625e-06f;  // 1 - 64u
 #ifndef RT_GEN_BLOCK
-#define RT_GEN_BLOCK 4
+#define RT_GEN_BLOCK 8
 #endif
 constexpr int kGenBlock = RT_GEN_BLOCK;                    // spheres per wave vote in the general loops
 
