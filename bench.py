@@ -338,12 +338,14 @@ def main():
             bound = FLOPS_PER_SHADOW_TEST * n_hits * n_point * objs.n * args.depth
             pv, pnote = pmc_summary(args.config, args.depth, True, "shadow_mask_kernel")
             sh_flops = pv.get("flops") if pv else None
+            if sh_flops:
+                sh_flops *= args.depth  # the summary averages the launches of one frame: one per iteration of renderer.rs:46
             shadow_info = {"no_early_out_bound_flops": bound, "executed_flops": sh_flops,
                            "executed_over_bound": (sh_flops / bound) if sh_flops else None,
                            "lane_utilisation": pv.get("lane_utilisation") if pv else None,
                            "source": ("counter-derived flops " + pnote) if sh_flops else pnote}
             kernels.append(("shadow_mask_kernel (+ record sort)", 1, sh_flops or 0.0, phase_ms[1],
-                            ("counter-derived: 64 x (2 FMA + ADD + MUL + TRANS) of the committed PMC pass = %.4g flops per launch, %.3f of the no-early-out bound "
+                            ("counter-derived: 64 x (2 FMA + ADD + MUL + TRANS) of the committed PMC pass = %.4g flops per frame, %.3f of the no-early-out bound "
                              "(%d per (shadow ray,sphere) filter test x %d hit records x %d point lights x %d spheres x %d iteration(s))" %
                              (sh_flops, sh_flops / bound, FLOPS_PER_SHADOW_TEST, n_hits, n_point, objs.n, args.depth)) if sh_flops else
                             "executed flops unknown (%s); no-early-out bound %.4g" % (pnote, bound)))
