@@ -552,9 +552,51 @@ __device__ __forceinline__ float wave_min(float v)
 
 constexpr float kConeP1 = 1.0f - 3.814697265625e-06f;  // P1 = 1 - 64u of the member test (scene_prep.cpp: prepare_light_filters)
 
+// The cone of the directions a wave holds: `fin` = the rays of `mask` whose direction (dx, dy, dz)[p] is finite (the others miss every
+// exact test and need no candidates); unit axis a = normalised sum of those directions; sinT >= sin and cosT <= cos of the largest
+// angle between a and one of them (|a x d| is accurate for small angles; 1e-6 relative and absolute slack).  Returns true if they
+// all lie within 60 degrees of a; false (NaN axis included) means "no cone": the caller keeps every sphere.
+template <int P>
+__device__ __forceinline__ bool wave_cone(uint32_t mask, const float (&dx)[P], const float (&dy)[P], const float (&dz)[P], uint32_t& fin, float& ax,
+                                          float& ay, float& az, float& sinT, float& cosT)
+{
+    ax = ay = az = 0.0f;
+    fin = 0u;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        if (((mask >> p) & 1u) && __builtin_isfinite(dx[p]) && __builtin_isfinite(dy[p]) && __builtin_isfinite(dz[p])) {
+            fin |= 1u << p;
+            ax = ax + dx[p];
+            ay = ay + dy[p];
+            az = az + dz[p];
+        }
+    }
+    ax = wave_sum(ax);
+    ay = wave_sum(ay);
+    az = wave_sum(az);
+    const float an = sqrtf(ax * ax + ay * ay + az * az);
+    ax = ax / an;
+    ay = ay / an;
+    az = az / an;
+    float cmin = INFINITY, smax = 0.0f;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        if (!((fin >> p) & 1u)) continue;
+        const float c = ax * dx[p] + ay * dy[p] + az * dz[p];
+        const float kx = ay * dz[p] - az * dy[p], ky = az * dx[p] - ax * dz[p], kz = ax * dy[p] - ay * dx[p];
+        cmin = __builtin_fminf(cmin, c);
+        smax = __builtin_fmaxf(smax, sqrtf(kx * kx + ky * ky + kz * kz));
+    }
+    cmin = wave_min(cmin);
+    smax = wave_max(smax);
+    sinT = smax * (1.0f + 1.0e-6f) + 1.0e-6f;
+    cosT = sqrtf(__builtin_fmaxf(0.0f, 1.0f - sinT * sinT)) * (1.0f - 1.0e-6f);
+    return an > 0.0f && an < INFINITY && cmin > 0.5f && cmin <= 2.0f;
+}
+
 // Occlusion bits of every (live record, point light) pair of this iteration, semantics of the oracle's occluded().  A persistent grid
-// whose WAVES pull tiles (64 * P consecutive entries of the spatially sorted record list, one word = 32 lights of the occlusion plane)
-// from the queue A.tile_ctr.  The wave computes its hit points once and then takes the lights one by one.
+// whose WAVES pull tiles (light l, 64 * P consecutive entries of the spatially sorted record list) from the queue A.tile_ctr, light-major.
+// (Several lights per tile, the hit points loaded once, measured slower: one light's constants at a time stay in every CU's caches.)
 // All rays toward one light end at the same point: seen from the light they share an origin and the primary loop's 3-FMA filter
 // applies with the per-light constants A.lfilt (P rays per lane, broadcast LDS reads, one wave vote per B spheres); candidates run the
 // reference's exact general-origin test on the ORIGINAL ray (h, u), so the result is bit-identical to the oracle's.
@@ -564,14 +606,13 @@ constexpr float kConeP1 = 1.0f - 3.814697265625e-06f;  // P1 = 1 - 64u of the me
 // wave's.  What is kept goes to a per-wave list in LDS and is walked with the 3-FMA filter; the wave leaves a light as soon as all
 // its rays are blocked (the early-out).  Neither vote ever drops a sphere that the per-ray filter would pass, so the bits equal those
 // of a walk over the whole list.  Waves whose rays do not fit a 60-degree cone (light next to the surface, records on far-apart
-// elements) open every cluster.  Result: bit (l & 31) of A.rec_occ[(l >> 5) * rec_cap + r] (a tile covers LC lights of one word; the
-// words are zeroed by launch_render unless a tile owns whole words, LC = 32).
+// elements) open every cluster.  Result: bit (l & 31) of A.rec_occ[(l >> 5) * rec_cap + r] (atomicOr; the words are zeroed by launch_render).
 // `far` marks rays whose hit point lies outside the ball the filter margins were derived for (only possible on planes): a wave that
 // holds one tests every sphere exactly.  No workgroup barrier anywhere: the four waves of a workgroup are independent.
-template <int P, int B, int CAP, int LC, int TB, int MG>
+template <int P, int B, int CAP, int TB>
 __global__ __launch_bounds__(kWaves * 64) void shadow_mask_kernel(const RenderArgs A)
 {
-    static_assert(CAP % B == 0 && CAP >= 128 && B % 4 == 0 && LC >= 1 && 32 % LC == 0, "shortlist geometry");
+    static_assert(CAP % B == 0 && CAP >= 128 && B % 4 == 0, "shortlist geometry");
     __shared__ __attribute__((aligned(16))) float s_list[kWaves][7 * CAP];  // per wave: filter x | y | z, then the sphere (cx, cy, cz, r) per entry
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
@@ -585,8 +626,7 @@ __global__ __launch_bounds__(kWaves * 64) void shadow_mask_kernel(const RenderAr
     const uint32_t live = A.rec_count[1];
     const uint32_t per_tile = 64 * P;
     const uint32_t groups = (live + per_tile - 1) / per_tile;
-    const uint32_t chunks = ((uint32_t)A.n_lights + LC - 1) / LC;
-    const uint32_t n_tiles = groups * chunks;
+    const uint32_t n_tiles = groups * (uint32_t)A.n_lights;
     const int n_cl = A.n_pad / 16;
     // Tiles come from the queue TB at a time: returning atomics on ONE address complete at only ~40-80 M/s chip-wide, a rate the small
     // tiles of this kernel would otherwise be bound by (tiles of either size took 12-14 ns each).  (Giving every wave its first TB
@@ -602,11 +642,12 @@ __global__ __launch_bounds__(kWaves * 64) void shadow_mask_kernel(const RenderAr
         }
         const uint32_t t = t_next++;
         if (t >= n_tiles) continue;
-        const uint32_t chunk = t / groups;  // chunk-major: waves that run together work on the same lights (their constants stay in the caches)
-        const uint32_t word = chunk * LC / 32u;
+        const int l = (int)(t / groups);  // light-major: waves that run together work on the same light (its constants stay in the caches)
         const uint32_t first = (t % groups) * per_tile;
+        const float4 lp = A.lpos[l];
+        if (A.lcol[l].w != 0.0f) continue;  // ambient lights are never shadowed
         float hx[P], hy[P], hz[P];
-        uint32_t rec[P], occw[P];
+        uint32_t rec[P];
         uint32_t okm = 0u, far = 0u;
 #pragma unroll
         for (int p = 0; p < P; ++p) {
@@ -614,7 +655,6 @@ __global__ __launch_bounds__(kWaves * 64) void shadow_mask_kernel(const RenderAr
             const bool ok = e < live;  // (the sorted list holds live records only)
             const size_t i = ok ? e : 0u;
             rec[p] = A.rec_perm[i];
-            occw[p] = 0u;
             if (ok) okm |= 1u << p;
             hx[p] = A.rec_hit[i];  // renderer.rs:57, computed by the scatter kernel
             hy[p] = A.rec_hit[(size_t)A.rec_cap + i];
@@ -625,10 +665,7 @@ __global__ __launch_bounds__(kWaves * 64) void shadow_mask_kernel(const RenderAr
             }
         }
         if (!A.n_planes) far = 0u;
-        const int l_end = min(A.n_lights, (int)(chunk * LC + LC));
-        for (int l = (int)(chunk * LC); l < l_end; ++l) {
-            const float4 lp = A.lpos[l];
-            if (A.lcol[l].w != 0.0f) continue;  // ambient lights are never shadowed
+        {
             float ux[P], uy[P], uz[P], sd[P], wx[P], wy[P], wz[P];
             uint32_t need = 0u;
 #pragma unroll
@@ -682,51 +719,21 @@ __global__ __launch_bounds__(kWaves * 64) void shadow_mask_kernel(const RenderAr
                 for (int a = A.lalways_off[l]; a < A.lalways_off[l + 1]; ++a) exact(A.sph_r[A.lalways[a]]);
                 uint32_t open = need & ~occ;
                 if (__builtin_amdgcn_ballot_w64(open != 0u) != 0ull) {
-                    // ---- the wave's cone: axis = normalised sum of the open rays' w, half-angle from the largest |a x w| ----
-                    float ax = 0.0f, ay = 0.0f, az = 0.0f;
-                    uint32_t fin = 0u;
+                    // ---- the wave's cone over the reversed directions of its open rays, and the longest of those rays ----
+                    float ax, ay, az, sinT, cosT, sdmax = 0.0f;
+                    uint32_t fin;
+                    const bool wide = !wave_cone<P>(open, wx, wy, wz, fin, ax, ay, az, sinT, cosT);
 #pragma unroll
-                    for (int p = 0; p < P; ++p) {
-                        const bool f = ((open >> p) & 1u) && __builtin_isfinite(wx[p]) && __builtin_isfinite(wy[p]) && __builtin_isfinite(wz[p]);
-                        if (f) {  // (a ray with a non-finite direction misses every exact test: it needs no candidates)
-                            fin |= 1u << p;
-                            ax = ax + wx[p];
-                            ay = ay + wy[p];
-                            az = az + wz[p];
-                        }
-                    }
-                    ax = wave_sum(ax);
-                    ay = wave_sum(ay);
-                    az = wave_sum(az);
-                    const float an = sqrtf(ax * ax + ay * ay + az * az);
-                    ax = ax / an;
-                    ay = ay / an;
-                    az = az / an;
-                    float cmin = INFINITY, smax = 0.0f, sdmax = 0.0f;
-#pragma unroll
-                    for (int p = 0; p < P; ++p) {
-                        if ((fin >> p) & 1u) {
-                            const float c = ax * wx[p] + ay * wy[p] + az * wz[p];
-                            const float kx = ay * wz[p] - az * wy[p], ky = az * wx[p] - ax * wz[p], kz = ax * wy[p] - ay * wx[p];
-                            cmin = __builtin_fminf(cmin, c);
-                            smax = __builtin_fmaxf(smax, sqrtf(kx * kx + ky * ky + kz * kz));
-                        }
+                    for (int p = 0; p < P; ++p)
                         if ((open >> p) & 1u) sdmax = __builtin_fmaxf(sdmax, sd[p]);
-                    }
-                    cmin = wave_min(cmin);
-                    smax = wave_max(smax);
                     sdmax = wave_max(sdmax);
-                    // every finite open ray lies within theta of a, theta < 60 deg, sin(theta) <= sinT, cos(theta) >= cosT (few-ulp slack)
-                    const bool wide = !(an > 0.0f && an < INFINITY && cmin > 0.5f && cmin <= 2.0f);
 #ifdef RT_MASK_STATS
                     if (lane == 0) {
                         atomicAdd(A.tile_ctr + 2, 1u);
                         if (wide) atomicAdd(A.tile_ctr + 3, 1u);
-                        atomicAdd(A.tile_ctr + 8, (uint32_t)(smax * 1000.0f));
+                        atomicAdd(A.tile_ctr + 8, (uint32_t)(sinT * 1000.0f));
                     }
 #endif
-                    const float sinT = smax * (1.0f + 1.0e-6f) + 1.0e-6f;
-                    const float cosT = sqrtf(__builtin_fmaxf(0.0f, 1.0f - sinT * sinT)) * (1.0f - 1.0e-6f);
                     const float4* const clA = A.lclA + (size_t)l * n_cl;
                     const float4* const clB = A.lclB + (size_t)l * n_cl;
                     const float4* const lf = A.lfilt + (size_t)l * A.n_pad;
@@ -813,37 +820,30 @@ __global__ __launch_bounds__(kWaves * 64) void shadow_mask_kernel(const RenderAr
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        // ---- member vote: 4 * MG open clusters at a time (16 lanes per cluster; MG loads per lane in flight together) ----
-                        for (int base = 0; base < n_open && going; base += 4 * MG) {
-                            float4 q[MG], sp[MG];
-#pragma unroll
-                            for (int i = 0; i < MG; ++i) {
-                                const int ci = base + 4 * i + (lane >> 4);
-                                const int j = (ci < n_open ? s_cl[ci] : 0) * 16 + (lane & 15);
-                                q[i] = ci < n_open ? lf[j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                                sp[i] = A.sph_o[j];  // the sphere itself, same spatial order: candidates are tested out of LDS, no dependent load
+                        // ---- member vote: four open clusters at a time, 16 lanes each ----
+                        for (int base = 0; base < n_open && going; base += 4) {
+                            const int ci = base + (lane >> 4);
+                            const int j = (ci < n_open ? s_cl[ci] : 0) * 16 + (lane & 15);
+                            const float4 q = ci < n_open ? lf[j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                            const float4 sp = A.sph_o[j];  // the sphere itself, same spatial order: candidates are tested out of LDS, no dependent load
+                            const float dot = __builtin_fmaf(ax, q.x, __builtin_fmaf(ay, q.y, az * q.z));
+                            const float rhs = __builtin_fmaf(cosT, kConeP1, -(sinT * q.w));
+                            const bool entry = q.x != 0.0f || q.y != 0.0f || q.z != 0.0f;  // all zero: padding / always-list / plane / no cluster
+                            const bool keep = entry && (wide || dot >= rhs - 8.0e-6f);
+                            const uint64_t km = __builtin_amdgcn_ballot_w64(keep);
+                            if (km == 0ull) continue;
+                            if (keep) {
+                                const int at = count + (int)lanes_below(km);
+                                s_x[at] = q.x;
+                                s_y[at] = q.y;
+                                s_z[at] = q.z;
+                                s_s[at] = sp;
                             }
-#pragma unroll
-                            for (int i = 0; i < MG; ++i) {
-                                const float dot = __builtin_fmaf(ax, q[i].x, __builtin_fmaf(ay, q[i].y, az * q[i].z));
-                                const float rhs = __builtin_fmaf(cosT, kConeP1, -(sinT * q[i].w));
-                                const bool entry = q[i].x != 0.0f || q[i].y != 0.0f || q[i].z != 0.0f;  // all zero: padding / always-list / plane / no cluster
-                                const bool keep = entry && (wide || dot >= rhs - 8.0e-6f);
-                                const uint64_t km = __builtin_amdgcn_ballot_w64(keep);
-                                if (km == 0ull || !going) continue;
-                                if (keep) {
-                                    const int at = count + (int)lanes_below(km);
-                                    s_x[at] = q[i].x;
-                                    s_y[at] = q[i].y;
-                                    s_z[at] = q[i].z;
-                                    s_s[at] = sp[i];
-                                }
-                                count += __builtin_popcountll(km);
+                            count += __builtin_popcountll(km);
 #ifdef RT_MASK_STATS
-                                if (lane == 0) atomicAdd(A.tile_ctr + 5, (uint32_t)__builtin_popcountll(km));
+                            if (lane == 0) atomicAdd(A.tile_ctr + 5, (uint32_t)__builtin_popcountll(km));
 #endif
-                                if (count > CAP - 64) going = walk();
-                            }
+                            if (count > CAP - 64) going = walk();
                         }
                         __builtin_amdgcn_wave_barrier();
                     }
@@ -851,15 +851,8 @@ __global__ __launch_bounds__(kWaves * 64) void shadow_mask_kernel(const RenderAr
                 }
             }
 #pragma unroll
-            for (int p = 0; p < P; ++p) occw[p] |= ((occ >> p) & 1u) << (l & 31);
-        }
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            if (LC == 32) {  // the tile owns the whole word
-                if ((okm >> p) & 1u) A.rec_occ[(size_t)word * A.rec_cap + rec[p]] = occw[p];
-            } else if (occw[p]) {
-                atomicOr(A.rec_occ + (size_t)word * A.rec_cap + rec[p], occw[p]);
-            }
+            for (int p = 0; p < P; ++p)
+                if ((occ >> p) & 1u) atomicOr(A.rec_occ + (size_t)(l >> 5) * A.rec_cap + rec[p], 1u << (l & 31));
         }
     }
     if (lane == 0) {  // re-arm the queue (see render_kernel); here every WAVE does exactly one failing fetch
@@ -917,42 +910,31 @@ __device__ __forceinline__ void trace_bundle(const RenderArgs& A, float* s_g, fl
         }
     }
     // ---- the bundle: origin ball and direction cone of the live rays with finite data (the others miss every exact test) ----
-    float sox = 0.0f, soy = 0.0f, soz = 0.0f, sdx = 0.0f, sdy = 0.0f, sdz = 0.0f, cnt = 0.0f;
-    uint32_t fin = 0u;
+    uint32_t finite_origin = 0u, fin;
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+        if (((need >> p) & 1u) && __builtin_isfinite(px[p]) && __builtin_isfinite(py[p]) && __builtin_isfinite(pz[p])) finite_origin |= 1u << p;
+    float ax, ay, az, sinT, cosT;
+    const bool narrow = wave_cone<P>(finite_origin, ux, uy, uz, fin, ax, ay, az, sinT, cosT);
+    float sox = 0.0f, soy = 0.0f, soz = 0.0f, cnt = 0.0f;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
-        const bool f = ((need >> p) & 1u) && __builtin_isfinite(px[p]) && __builtin_isfinite(py[p]) && __builtin_isfinite(pz[p]) &&
-                       __builtin_isfinite(ux[p]) && __builtin_isfinite(uy[p]) && __builtin_isfinite(uz[p]);
-        if (f) {
-            fin |= 1u << p;
-            sox = sox + px[p]; soy = soy + py[p]; soz = soz + pz[p];
-            sdx = sdx + ux[p]; sdy = sdy + uy[p]; sdz = sdz + uz[p];
-            cnt = cnt + 1.0f;
-        }
+        if (!((fin >> p) & 1u)) continue;
+        sox = sox + px[p]; soy = soy + py[p]; soz = soz + pz[p];
+        cnt = cnt + 1.0f;
     }
     cnt = wave_sum(cnt);
     if (!(cnt > 0.0f)) return;  // (wave-uniform)
     const float ocx = wave_sum(sox) / cnt, ocy = wave_sum(soy) / cnt, ocz = wave_sum(soz) / cnt;
-    float ax = wave_sum(sdx), ay = wave_sum(sdy), az = wave_sum(sdz);
-    const float an = sqrtf(ax * ax + ay * ay + az * az);
-    ax = ax / an; ay = ay / an; az = az / an;
-    float ro = 0.0f, cmin = INFINITY, smax = 0.0f;
+    float ro = 0.0f;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
         if (!((fin >> p) & 1u)) continue;
         const float ex = px[p] - ocx, ey = py[p] - ocy, ez = pz[p] - ocz;
         ro = __builtin_fmaxf(ro, sqrtf(ex * ex + ey * ey + ez * ez));
-        const float c = ax * ux[p] + ay * uy[p] + az * uz[p];
-        const float kx = ay * uz[p] - az * uy[p], ky = az * ux[p] - ax * uz[p], kz = ax * uy[p] - ay * ux[p];
-        cmin = __builtin_fminf(cmin, c);
-        smax = __builtin_fmaxf(smax, sqrtf(kx * kx + ky * ky + kz * kz));
     }
     ro = wave_max(ro) * (1.0f + 1.0e-5f) + 1.0e-30f;
-    cmin = wave_min(cmin);
-    smax = wave_max(smax);
-    const bool wide = !(an > 0.0f && an < INFINITY && cmin > 0.5f && cmin <= 2.0f && ro < INFINITY);
-    const float sinT = smax * (1.0f + 1.0e-6f) + 1.0e-6f;
-    const float cosT = sqrtf(__builtin_fmaxf(0.0f, 1.0f - sinT * sinT)) * (1.0f - 1.0e-6f);
+    const bool wide = !(narrow && ro < INFINITY);
     const float on_ = sqrtf(ocx * ocx + ocy * ocy + ocz * ocz) + ro;  // >= |o'| of every ray of the bundle
     const float E = 9.5367431640625e-06f * (on_ * on_ + A.ball[3] * 1.0021f);  // 160 u (|o'|^2 + |c'|^2): A.ball[3] = 0.998 Rs^2 >= ... |c'|^2 <= Rs^2
     const float sqrtE = sqrtf(E);
@@ -1262,18 +1244,10 @@ constexpr int kShadeCap = RT_SHADE_CAP;  // entries of the per-wave sphere list 
 #define RT_MASK_P 4
 #endif
 constexpr int kMaskP = RT_MASK_P;   // shadow rays per lane in shadow_mask_kernel
-#ifndef RT_MASK_LC
-#define RT_MASK_LC 1
-#endif
-constexpr int kMaskLC = RT_MASK_LC; // lights per tile of shadow_mask_kernel
 #ifndef RT_MASK_TB
 #define RT_MASK_TB 4
 #endif
 constexpr int kMaskTB = RT_MASK_TB; // tiles a wave takes from the queue per atomic
-#ifndef RT_MASK_MG
-#define RT_MASK_MG 1
-#endif
-constexpr int kMaskMG = RT_MASK_MG; // member loads per lane in flight together in shadow_mask_kernel (4 * MG open clusters per step)
 
 }  // namespace
 
@@ -1343,7 +1317,7 @@ hipError_t primary_slots(uint32_t& slots)
 hipError_t mask_slots_of_device(uint32_t& slots)
 {
     static uint32_t cache[64] = {};
-    return resident_slots(shadow_mask_kernel<kMaskP, kShadowB, kShadowCap, kMaskLC, kMaskTB, kMaskMG>, cache, slots, kMaskLdsPad);
+    return resident_slots(shadow_mask_kernel<kMaskP, kShadowB, kShadowCap, kMaskTB>, cache, slots, kMaskLdsPad);
 }
 
 // Cut the band into the three tile sections of render_kernel and launch the persistent grid.
@@ -1422,12 +1396,12 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream, PhaseEvents
         }
         if (shadows) {
             // only the words of this band's records (at most npix per plane), not the whole capacity of the scratch
-            if (kMaskLC != 32 && (e = clear_words(a.rec_occ, (size_t)npix, a.rec_cap, occ_words, nullptr, 0, stream)) != hipSuccess) return e;
-            const uint64_t worst_tiles = (npix + 64 * kMaskP - 1) / (64 * kMaskP) * (uint64_t)(((uint32_t)args.n_lights + kMaskLC - 1) / kMaskLC);
+            if ((e = clear_words(a.rec_occ, (size_t)npix, a.rec_cap, occ_words, nullptr, 0, stream)) != hipSuccess) return e;
+            const uint64_t worst_tiles = (npix + 64 * kMaskP - 1) / (64 * kMaskP) * (uint64_t)args.n_lights;
             if (worst_tiles >= (1ull << 32)) return hipErrorInvalidValue;  // the tile queue counts in 32 bits
             const uint64_t worst_wgs = (worst_tiles + kWaves - 1) / kWaves;
             const uint32_t grid = worst_wgs < mask_slots ? (uint32_t)worst_wgs : mask_slots;
-            hipLaunchKernelGGL((shadow_mask_kernel<kMaskP, kShadowB, kShadowCap, kMaskLC, kMaskTB, kMaskMG>), dim3(grid), dim3(kWaves * 64), kMaskLdsPad, stream, a);
+            hipLaunchKernelGGL((shadow_mask_kernel<kMaskP, kShadowB, kShadowCap, kMaskTB>), dim3(grid), dim3(kWaves * 64), kMaskLdsPad, stream, a);
             if ((e = hipGetLastError()) != hipSuccess) return e;
         }
         const bool timed = phases && it < kPhaseIters;
