@@ -46,6 +46,12 @@ extern "C" {
 #define RT_TIMED 4u    /* rt_render_rows_device only: record HIP events around the launch (and between its kernels) for rt_last_kernel_ms /
                           rt_last_phase_ms.  Off by default: an event costs ~4 us of GPU time between back-to-back launches (1.3 % of a
                           C3 frame for the pair).  The blocking host-output entry points always time their kernels; ignored elsewhere. */
+#define RT_CULL 8u     /* OPT-IN, same bytes out: the primary rays skip the walk over the whole element list.  A wave's 16 x 16 pixel tile
+                          is a narrow cone of directions from the common origin (renderer.rs:43), so clusters of spheres and then single
+                          spheres outside that cone are voted out before the per-pixel filter and the exact test of object/sphere.rs:26-44
+                          run on what is left.  Off by default: the default path is the per-pixel walk of the object list
+                          that renderer.rs:48-54 is, measured against the FP32 roofline; with RT_CULL a C3 frame takes a fraction of the
+                          time and no FLOP roofline applies. */
 
 /* shadow-ray acceptance window of the RT_SHADOWS extension: occluded iff RT_SHADOW_EPS < t < distance(light) */
 #define RT_SHADOW_EPS 1.0e-3f
@@ -210,6 +216,15 @@ int32_t rt_debug_prepare_spheres(const rt_objects* objects, float* filt, uint8_t
  */
 int32_t rt_debug_prepare_shadow_cull(const rt_objects* objects, const rt_lights* lights, int32_t light, int32_t* order, float* lfilt,
                                      float* cl_a, float* cl_b, int32_t* always, int32_t* n_always);
+
+/*
+ * Host-only introspection of the RT_CULL hierarchy rt_scene_upload builds for the primary rays (no device needed; used by the CPU tests;
+ * no reference counterpart).  With n_pad = n rounded up to 16 (at least 16): order[n_pad] = element at position j of the direction order
+ * (-1 = no entry: padding, planes, spheres the primary filter cannot cover); pfilt[4*n_pad] = per position (cx', cy', cz', P2): the primary
+ * filter d.c' - 1 >= 0 of rt_debug_prepare_spheres and the constant of the member cone test; cl_a / cl_b[4*n_pad/16] = per cluster of 16
+ * positions (cone axis, 0) and (cos, sin of its half-angle).  See DESIGN.md 3.5.
+ */
+int32_t rt_debug_prepare_primary_cull(const rt_objects* objects, int32_t* order, float* pfilt, float* cl_a, float* cl_b);
 
 /*
  * Host-only introspection of how a band of `rows` rows x `w` columns is cut into the tile queue of the primary kernel when the

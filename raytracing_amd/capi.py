@@ -23,6 +23,7 @@ RT_AMBIENT = 1
 RT_SHADOWS = 1
 RT_OUT_RGB8 = 2
 RT_TIMED = 4  # rt_render_rows_device: record the events rt_last_kernel_ms / rt_last_phase_ms read
+RT_CULL = 8  # opt-in: primary rays through the cone hierarchy instead of the walk over the whole list (same bytes out)
 RT_SHADOW_EPS = 1.0e-3
 RT_NOALLOC_SCRATCH_BYTES = 32 << 20
 
@@ -34,6 +35,7 @@ EXPORTS = (
     "rt_scene_upload", "rt_render", "rt_render_rows", "rt_render_rows_device", "rt_last_kernel_ms",
     "rt_debug_prepare_spheres", "rt_host_alloc", "rt_host_free", "rt_debug_tile_plan", "rt_render_rows_device_noalloc", "rt_last_phase_ms", "rt_ctx_create_multi", "rt_transform_apply",
     "rt_debug_prepare_shadow_cull",
+    "rt_debug_prepare_primary_cull",
 )
 
 _f32p = C.POINTER(C.c_float)
@@ -97,6 +99,7 @@ def load() -> C.CDLL:
     lib.rt_debug_prepare_spheres.argtypes = [C.POINTER(RtObjects), _f32p, _u8p]
     _i32p = C.POINTER(C.c_int32)
     lib.rt_debug_prepare_shadow_cull.argtypes = [C.POINTER(RtObjects), C.POINTER(RtLights), C.c_int32, _i32p, _f32p, _f32p, _f32p, _i32p, _i32p]
+    lib.rt_debug_prepare_primary_cull.argtypes = [C.POINTER(RtObjects), _i32p, _f32p, _f32p, _f32p]
     for name in EXPORTS:
         if name not in ("rt_version", "rt_last_error"):
             getattr(lib, name).restype = C.c_int32
@@ -219,6 +222,21 @@ def debug_prepare_shadow_cull(objs: FlatObjects, lights: FlatLights, light: int)
     if rc != RT_OK:
         raise RtError(rc, "rt_debug_prepare_shadow_cull")
     return {"order": order, "lfilt": lfilt, "cl_a": cl_a, "cl_b": cl_b, "always": always[: n_always.value]}
+
+
+def debug_prepare_primary_cull(objs: FlatObjects) -> dict:
+    """Host-only: the cone hierarchy of RT_CULL for the primary rays (rt_debug_prepare_primary_cull)."""
+    n_pad = max(16, (objs.n + 15) // 16 * 16)
+    order = np.zeros(n_pad, dtype=np.int32)
+    pfilt = np.zeros((n_pad, 4), dtype=np.float32)
+    cl_a = np.zeros((n_pad // 16, 4), dtype=np.float32)
+    cl_b = np.zeros((n_pad // 16, 4), dtype=np.float32)
+    o = objs.c_struct()
+    rc = load().rt_debug_prepare_primary_cull(C.byref(o), order.ctypes.data_as(C.POINTER(C.c_int32)), pfilt.ctypes.data_as(_f32p),
+                                              cl_a.ctypes.data_as(_f32p), cl_b.ctypes.data_as(_f32p))
+    if rc != RT_OK:
+        raise RtError(rc, "rt_debug_prepare_primary_cull")
+    return {"order": order, "pfilt": pfilt, "cl_a": cl_a, "cl_b": cl_b}
 
 
 class Context:

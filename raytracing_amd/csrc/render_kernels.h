@@ -11,7 +11,7 @@ struct RenderArgs {
     uint32_t w, h;    // full frame size (ray formula uses global pixel indices, display.rs:99)
     uint32_t y0, y1;  // row band rendered by this launch
     uint32_t depth;   // renderer.rs:32
-    uint32_t flags;   // RT_SHADOWS | RT_OUT_RGB8
+    uint32_t flags;   // RT_SHADOWS | RT_OUT_RGB8 | RT_CULL
     int32_t n, n_pad, n_always, n_lights;
     const float4* filt;     // n_pad
     const float4* sph;      // n_pad (cx,cy,cz,k)
@@ -30,6 +30,10 @@ struct RenderArgs {
     const int32_t* rank;        // n_pad: spatial position of element i (sort key of the hit records)
     const int32_t* lalways;     // per-light always-test lists, concatenated
     const int32_t* lalways_off; // n_lights + 1
+    const int32_t* porder;      // RT_CULL, n_pad: element at position j of the primary rays' direction order, -1 = no entry
+    const float4* pfilt_o;      // RT_CULL, n_pad: filt in that order, w = P2 of the member test; all zero = no entry
+    const float4* pclA;         // RT_CULL, n_pad / 16: per cluster of 16 positions (cone axis x, y, z, 0)
+    const float4* pclB;         // RT_CULL, n_pad / 16: (cos, sin of the cluster's half-angle, 0, 0)
     const float4* pln;          // n_pad: (nx, ny, nz, 1) for RT_PLANE elements (extension), 0 for spheres
     const int32_t* planes;      // n_planes indices of the plane elements (tested exactly for every ray)
     int32_t n_planes;

@@ -209,6 +209,61 @@ __device__ __forceinline__ void store_pixel(const RenderArgs& A, size_t pix, flo
     }
 }
 
+// The end of a tile, given every pixel's closest hit: EMIT = false: shade (depth 1, no shadows) and store the pixel — the whole reference
+// path.  EMIT = true: store black, and append every hit as a record (pixel, element, t) to a dense list for the general-ray kernels
+// below (bounces / shadow rays then run with full lanes instead of the frame's ~20 % coverage).
+template <int P, bool EMIT>
+__device__ __forceinline__ void finish_tile(const RenderArgs& A, int lane, uint32_t inb, uint32_t x_base, uint32_t y_base, const float (&dx)[P],
+                                            const float (&dy)[P], const float (&dz)[P], const float (&best_t)[P], const int (&best_i)[P])
+{
+    if (!EMIT) {
+        // ---- shading and store (depth 1, reference semantics) ----
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const bool hit = best_i[p] >= 0;
+            // renderer.rs:57, object/mod.rs:61-63 — origin + t * direction (origin = 0)
+            const float px = 0.0f + best_t[p] * dx[p], py = 0.0f + best_t[p] * dy[p], pz = 0.0f + best_t[p] * dz[p];
+            float r = 0.0f, g = 0.0f, b = 0.0f;
+            if (__builtin_amdgcn_ballot_w64(hit) != 0ull) shade(A, hit, best_i[p], px, py, pz, r, g, b);  // most waves see only background
+            if (!((inb >> p) & 1u)) continue;
+            const uint32_t y = y_base + kLY * p;
+            const size_t pix = (size_t)(y - A.y0) * A.w + x_base;
+            store_pixel(A, pix, hit ? r : 0.0f, hit ? g : 0.0f, hit ? b : 0.0f);
+            if (A.hit_idx) A.hit_idx[pix] = best_i[p];
+        }
+    } else {
+        // ---- black background + dense hit records: one atomic per wave, order inside the list is irrelevant to the image ----
+        uint32_t total = 0;
+        uint64_t hitmask[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            hitmask[p] = __builtin_amdgcn_ballot_w64(((inb >> p) & 1u) && best_i[p] >= 0);
+            total += (uint32_t)__builtin_popcountll(hitmask[p]);
+        }
+        uint32_t base = 0;
+        if (lane == 0 && total) base = atomicAdd(A.rec_count, total);
+        base = __builtin_amdgcn_readfirstlane(base);
+        uint32_t off = base;
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const bool in_frame = (inb >> p) & 1u;
+            const uint32_t y = y_base + kLY * p;
+            const size_t pix = (size_t)(y - A.y0) * A.w + x_base;
+            if (in_frame) {
+                store_pixel(A, pix, 0.0f, 0.0f, 0.0f);
+                if (A.hit_idx) A.hit_idx[pix] = best_i[p];
+                if (best_i[p] >= 0) {
+                    const uint32_t r = off + __builtin_amdgcn_mbcnt_hi((uint32_t)(hitmask[p] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hitmask[p], 0u));
+                    A.rec_pix[r] = (uint32_t)pix;
+                    A.rec_idx[r] = best_i[p];
+                    A.rec_t[r] = best_t[p];
+                }
+            }
+            off += (uint32_t)__builtin_popcountll(hitmask[p]);
+        }
+    }
+}
+
 // Primary rays of ONE tile (a workgroup's 4 waves side by side: 64 x (4*PY) pixels, PY pixels per lane in one column): closest
 // hit over the whole list.  EMIT = false: shade (depth 1, no shadows) and store the pixel — the whole reference path.
 // EMIT = true: store black, and append every hit as a record (pixel, element, t) to a dense list for the general-ray kernels below
@@ -319,52 +374,7 @@ __device__ __forceinline__ void render_tile(const RenderArgs& A, float* s_x, flo
         }
     }
 
-    if (!EMIT) {
-        // ---- shading and store (depth 1, reference semantics) ----
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            const bool hit = best_i[p] >= 0;
-            // renderer.rs:57, object/mod.rs:61-63 — origin + t * direction (origin = 0)
-            const float px = 0.0f + best_t[p] * dx[p], py = 0.0f + best_t[p] * dy[p], pz = 0.0f + best_t[p] * dz[p];
-            float r = 0.0f, g = 0.0f, b = 0.0f;
-            if (__builtin_amdgcn_ballot_w64(hit) != 0ull) shade(A, hit, best_i[p], px, py, pz, r, g, b);  // most waves see only background
-            if (!((inb >> p) & 1u)) continue;
-            const uint32_t y = y_base + kLY * p;
-            const size_t pix = (size_t)(y - A.y0) * A.w + x_base;
-            store_pixel(A, pix, hit ? r : 0.0f, hit ? g : 0.0f, hit ? b : 0.0f);
-            if (A.hit_idx) A.hit_idx[pix] = best_i[p];
-        }
-    } else {
-        // ---- black background + dense hit records: one atomic per wave, order inside the list is irrelevant to the image ----
-        uint32_t total = 0;
-        uint64_t hitmask[P];
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            hitmask[p] = __builtin_amdgcn_ballot_w64(((inb >> p) & 1u) && best_i[p] >= 0);
-            total += (uint32_t)__builtin_popcountll(hitmask[p]);
-        }
-        uint32_t base = 0;
-        if (lane == 0 && total) base = atomicAdd(A.rec_count, total);
-        base = __builtin_amdgcn_readfirstlane(base);
-        uint32_t off = base;
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            const bool in_frame = (inb >> p) & 1u;
-            const uint32_t y = y_base + kLY * p;
-            const size_t pix = (size_t)(y - A.y0) * A.w + x_base;
-            if (in_frame) {
-                store_pixel(A, pix, 0.0f, 0.0f, 0.0f);
-                if (A.hit_idx) A.hit_idx[pix] = best_i[p];
-                if (best_i[p] >= 0) {
-                    const uint32_t r = off + __builtin_amdgcn_mbcnt_hi((uint32_t)(hitmask[p] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hitmask[p], 0u));
-                    A.rec_pix[r] = (uint32_t)pix;
-                    A.rec_idx[r] = best_i[p];
-                    A.rec_t[r] = best_t[p];
-                }
-            }
-            off += (uint32_t)__builtin_popcountll(hitmask[p]);
-        }
-    }
+    finish_tile<P, EMIT>(A, lane, inb, x_base, y_base, dx, dy, dz, best_t, best_i);
 }
 
 // The primary-ray kernel: a PERSISTENT grid (one workgroup per resident slot of the chip, launch_render) whose workgroups pull
@@ -592,6 +602,192 @@ __device__ __forceinline__ bool wave_cone(uint32_t mask, const float (&dx)[P], c
     sinT = smax * (1.0f + 1.0e-6f) + 1.0e-6f;
     cosT = sqrtf(__builtin_fmaxf(0.0f, 1.0f - sinT * sinT)) * (1.0f - 1.0e-6f);
     return an > 0.0f && an < INFINITY && cmin > 0.5f && cmin <= 2.0f;
+}
+
+// The cone of a TILE of primary rays without any cross-lane reduction: pos = M v is affine in the pixel coordinates (display.rs:98-100), so
+// the directions of a wave's pixel rectangle lie in the convex cone spanned by its four CORNER directions, and for every x of that cone
+// cos(angle(a, x)) >= the smallest cos(angle(a, corner)) as long as all four are positive.  The corners are held by lanes 0 and 15 (first
+// row, ray slot 0) and 48 and 63 (last row, ray slot P - 1) — clamped pixels at the frame's edge included — and are read with
+// v_readlane; everything after that is wave-uniform.  sinT carries 4e-6 of absolute slack: the f32 roundings of v, pos and unit()
+// move a direction by a few 1e-7 off the affine model.  Returns false ("no cone": the caller keeps every sphere) if a corner is not
+// finite or the corners do not fit within 60 degrees of their normalised sum.
+template <int P>
+__device__ __forceinline__ bool tile_cone(const float (&dx)[P], const float (&dy)[P], const float (&dz)[P], float& ax, float& ay, float& az,
+                                          float& sinT, float& cosT)
+{
+    auto corner = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+    const float gx[4] = {corner(dx[0], 0), corner(dx[0], 15), corner(dx[P - 1], 48), corner(dx[P - 1], 63)};
+    const float gy[4] = {corner(dy[0], 0), corner(dy[0], 15), corner(dy[P - 1], 48), corner(dy[P - 1], 63)};
+    const float gz[4] = {corner(dz[0], 0), corner(dz[0], 15), corner(dz[P - 1], 48), corner(dz[P - 1], 63)};
+    ax = (gx[0] + gx[1]) + (gx[2] + gx[3]);
+    ay = (gy[0] + gy[1]) + (gy[2] + gy[3]);
+    az = (gz[0] + gz[1]) + (gz[2] + gz[3]);
+    const float an = sqrtf(ax * ax + ay * ay + az * az);
+    ax = ax / an;
+    ay = ay / an;
+    az = az / an;
+    float cmin = INFINITY, smax = 0.0f;
+    bool finite = true;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        finite = finite && __builtin_isfinite(gx[i]) && __builtin_isfinite(gy[i]) && __builtin_isfinite(gz[i]);
+        const float c = ax * gx[i] + ay * gy[i] + az * gz[i];
+        const float kx = ay * gz[i] - az * gy[i], ky = az * gx[i] - ax * gz[i], kz = ax * gy[i] - ay * gx[i];
+        cmin = __builtin_fminf(cmin, c);
+        smax = __builtin_fmaxf(smax, sqrtf(kx * kx + ky * ky + kz * kz));
+    }
+    sinT = smax * (1.0f + 1.0e-6f) + 4.0e-6f;
+    cosT = sqrtf(__builtin_fmaxf(0.0f, 1.0f - sinT * sinT)) * (1.0f - 1.0e-6f);
+    return finite && an > 0.0f && an < INFINITY && cmin > 0.5f && cmin <= 2.0f;
+}
+
+// ---- RT_CULL: the primary rays through the cone hierarchy ------------------------------------------------------------------------------
+// Same image as render_kernel, byte for byte, without the walk over the whole list: a wave's tile (16 x 16 pixels, 4 per lane) is a
+// narrow cone of directions from the common origin 0, so the votes of the shadow rays apply with the "light" at the origin and the
+// primary filter's own constants (scene_prep.cpp: prepare_primary_cull; spheres ordered by the direction they are seen in, clusters of
+// 16).  Cluster vote -> member vote -> a per-wave list in LDS (c', element index) -> the 3-FMA filter of the hot loop, 8 spheres per
+// wave vote -> the reference's exact test for candidates -> closest hit as the lexicographic minimum of (t, index), so the list order
+// is immaterial.  Neither vote drops a sphere the per-pixel filter would pass.  Spheres on the always-list and planes are tested
+// exactly for every pixel, as in render_tile.  A plain grid, one tile (4 waves side by side: 64 x 16 pixels) per workgroup: tiles are
+// microseconds long, a queue would be bound by its atomic.  No workgroup barrier: the waves are independent.
+template <bool EMIT, int CAP>
+__global__ __launch_bounds__(kWaves * 64) void render_cull_kernel(const RenderArgs A)
+{
+    constexpr int P = 4, B = 8;
+    static_assert(CAP % B == 0 && CAP >= 128, "list geometry");
+    __shared__ float4 s_list[kWaves][CAP];  // per wave: (c'x, c'y, c'z, element index as bits)
+    __shared__ int s_open[kWaves][256];     // per wave: the clusters the current vote opened
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    float4* const s_l = s_list[wave];
+    int* const s_cl = s_open[wave];
+    const uint32_t t = blockIdx.x;
+    const uint32_t x_base = (t % A.strips) * (kWaves * kLX) + (uint32_t)(wave * kLX + (lane & (kLX - 1)));
+    const uint32_t y_base = A.y0 + (t / A.strips) * (4 * kLY) + (uint32_t)(lane >> 4);
+    if ((t % A.strips) * (kWaves * kLX) + (uint32_t)(wave * kLX) >= A.w) return;  // (wave-uniform) this wave's 16 columns lie beyond the frame
+
+    float dx[P], dy[P], dz[P], best_t[P];
+    int best_i[P];
+    uint32_t inb = 0;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        uint32_t x = x_base;
+        uint32_t y = y_base + kLY * p;
+        if (x < A.w && y < A.y1) inb |= 1u << p;
+        x = min(x, A.w - 1u);
+        y = min(y, A.y1 - 1u);
+        primary_dir(A, x, y, dx[p], dy[p], dz[p]);
+        best_t[p] = 0.0f;
+        best_i[p] = -1;
+    }
+    for (int a = 0; a < A.n_always; ++a) {  // spheres the filter cannot cover: exact test for every pixel
+        const int k = A.always[a];
+        const float4 s = A.sph[k];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            float tt;
+            const bool h = hit_primary_exact(dx[p], dy[p], dz[p], s, tt);
+            take_closest(h, tt, k, best_t[p], best_i[p]);
+        }
+    }
+    for (int a = 0; a < A.n_planes; ++a) {  // planes (extension): no filter, exact test for every pixel
+        const int k = A.planes[a];
+        const float4 p0 = A.sph_r[k], n = A.pln[k];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            float tt;
+            const bool h = hit_plane_exact(0.0f, 0.0f, 0.0f, dx[p], dy[p], dz[p], p0, n, tt);
+            take_closest(h, tt, k, best_t[p], best_i[p]);
+        }
+    }
+    // ---- the cone of the tile's directions (a ray with a non-finite direction misses every exact test and needs no candidates) ----
+    float ax, ay, az, sinT, cosT;
+    const bool wide = !tile_cone<P>(dx, dy, dz, ax, ay, az, sinT, cosT);
+    {
+        int count = 0;
+        auto walk = [&]() {
+            const int padded = (count + B - 1) / B * B;
+            if (count + lane < padded) s_l[count + lane] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // entries that never pass
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int s0 = 0; s0 < padded; s0 += B) {
+                float m = -1.0f;
+                float4 q[B];
+#pragma unroll
+                for (int b = 0; b < B; ++b) q[b] = s_l[s0 + b];  // wave-uniform address: broadcast ds_read_b128
+#pragma unroll
+                for (int b = 0; b < B; ++b)
+#pragma unroll
+                    for (int p = 0; p < P; ++p)
+                        m = __builtin_fmaxf(m, __builtin_fmaf(dx[p], q[b].x, __builtin_fmaf(dy[p], q[b].y, __builtin_fmaf(dz[p], q[b].z, -1.0f))));
+                if (__builtin_amdgcn_ballot_w64(m >= 0.0f) == 0ull) continue;
+#pragma unroll
+                for (int b = 0; b < B; ++b) {
+                    float mb = -1.0f;
+#pragma unroll
+                    for (int p = 0; p < P; ++p)
+                        mb = __builtin_fmaxf(mb, __builtin_fmaf(dx[p], q[b].x, __builtin_fmaf(dy[p], q[b].y, __builtin_fmaf(dz[p], q[b].z, -1.0f))));
+                    if (__builtin_amdgcn_ballot_w64(mb >= 0.0f) == 0ull) continue;
+                    const int k = __float_as_int(q[b].w);
+                    const float4 s = A.sph[k];
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
+                        float tt;
+                        const bool h = hit_primary_exact(dx[p], dy[p], dz[p], s, tt);
+                        take_closest(h, tt, k, best_t[p], best_i[p]);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            count = 0;
+        };
+        const int n_cl = A.n_pad / 16;
+        for (int cb = 0; cb < n_cl; cb += 256) {
+            // ---- cluster vote: up to four clusters per lane, their loads in flight together; open clusters -> s_cl ----
+            float4 ca[4], cs[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = cb + 64 * i + lane;
+                ca[i] = c < n_cl ? A.pclA[c] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                cs[i] = c < n_cl ? A.pclB[c] : make_float4(2.0f, 0.0f, 0.0f, 0.0f);
+            }
+            int n_open = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = cb + 64 * i + lane;
+                const float dot = __builtin_fmaf(ax, ca[i].x, __builtin_fmaf(ay, ca[i].y, az * ca[i].z));
+                const float rhs = __builtin_fmaf(cosT, cs[i].x, -(sinT * cs[i].y));
+                const bool pass = c < n_cl && (wide || dot >= rhs - 4.0e-6f);
+                const uint64_t mask = __builtin_amdgcn_ballot_w64(pass);
+                if (pass) s_cl[n_open + (int)lanes_below(mask)] = c;
+                n_open += __builtin_popcountll(mask);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // ---- member vote: four open clusters at a time, 16 lanes each ----
+            for (int base = 0; base < n_open; base += 4) {
+                const int ci = base + (lane >> 4);
+                const int j = (ci < n_open ? s_cl[ci] : 0) * 16 + (lane & 15);
+                const float4 q = ci < n_open ? A.pfilt_o[j] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                const int k = A.porder[j];
+                const float dot = __builtin_fmaf(ax, q.x, __builtin_fmaf(ay, q.y, az * q.z));
+                const float rhs = __builtin_fmaf(cosT, kConeP1, -(sinT * q.w));
+                const bool entry = q.x != 0.0f || q.y != 0.0f || q.z != 0.0f;  // all zero: no entry at this position
+                const bool keep = entry && (wide || dot >= rhs - 8.0e-6f);
+                const uint64_t km = __builtin_amdgcn_ballot_w64(keep);
+                if (km == 0ull) continue;
+                if (keep) s_l[count + (int)lanes_below(km)] = make_float4(q.x, q.y, q.z, __int_as_float(k));
+                count += __builtin_popcountll(km);
+                if (count > CAP - 64) walk();
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (count > 0) walk();
+    }
+    finish_tile<P, EMIT>(A, lane, inb, x_base, y_base, dx, dy, dz, best_t, best_i);
 }
 
 // Occlusion bits of every (live record, point light) pair of this iteration, semantics of the oracle's occluded().  A persistent grid
@@ -1314,6 +1510,23 @@ hipError_t primary_slots(uint32_t& slots)
     return resident_slots(render_kernel<kB, EMIT>, cache, slots);
 }
 
+#ifndef RT_CULL_CAP
+#define RT_CULL_CAP 128
+#endif
+constexpr int kCullCap = RT_CULL_CAP;  // entries of the per-wave sphere list of render_cull_kernel (16 B each in LDS)
+
+// RT_CULL: a plain grid of 64 x 16 pixel tiles, one per workgroup.
+template <bool EMIT>
+hipError_t launch_primary_cull(RenderArgs a, hipStream_t stream)
+{
+    if (!a.pfilt_o || !a.porder || !a.pclA || !a.pclB) return hipErrorInvalidValue;
+    a.strips = (a.w + kWaves * kLX - 1) / (kWaves * kLX);
+    const uint64_t n_tiles = (uint64_t)a.strips * ((a.y1 - a.y0 + 4 * kLY - 1) / (4 * kLY));
+    if (n_tiles >= (1ull << 31)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((render_cull_kernel<EMIT, kCullCap>), dim3((uint32_t)n_tiles), dim3(kWaves * 64), 0, stream, a);
+    return hipGetLastError();
+}
+
 hipError_t mask_slots_of_device(uint32_t& slots)
 {
     static uint32_t cache[64] = {};
@@ -1361,7 +1574,8 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream, PhaseEvents
 {
     if (phases) phases->iters = 0;
     if (args.y1 <= args.y0 || args.w == 0) return hipSuccess;
-    if (!is_general(args)) return launch_primary<false>(args, stream);
+    const bool cull = (args.flags & RT_CULL) != 0u;
+    if (!is_general(args)) return cull ? launch_primary_cull<false>(args, stream) : launch_primary<false>(args, stream);
 
     const bool shadows = (args.flags & RT_SHADOWS) != 0u && args.n_lights > 0;
     const uint64_t npix = (uint64_t)(args.y1 - args.y0) * args.w;
@@ -1371,7 +1585,7 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream, PhaseEvents
     hipError_t e = clear_words(nullptr, 0, 0, 0, args.rec_count, 1, stream);
     if (e != hipSuccess) return e;
     if (phases && (e = hipEventRecord(phases->ev[0], stream)) != hipSuccess) return e;
-    if ((e = launch_primary<true>(args, stream)) != hipSuccess) return e;
+    if ((e = cull ? launch_primary_cull<true>(args, stream) : launch_primary<true>(args, stream)) != hipSuccess) return e;
     if (phases && (e = hipEventRecord(phases->ev[1], stream)) != hipSuccess) return e;
 
     // The record count lives on the device: the grids below are sized for the worst case (every pixel of the band hit) or persistent,
@@ -1427,7 +1641,7 @@ void render_scratch_layout(const RenderArgs& args, bool& need_state, uint32_t& o
 
 const char* render_kernel_name(const RenderArgs& args)
 {
-    if (!is_general(args)) return "render_kernel<primary>";
+    if (!is_general(args)) return (args.flags & RT_CULL) ? "render_cull_kernel<primary>" : "render_kernel<primary>";
     return (args.flags & RT_SHADOWS) ? "render_kernel<emit> + shadow_mask_kernel + shade_iter_kernel" : "render_kernel<emit> + shade_iter_kernel";
 }
 

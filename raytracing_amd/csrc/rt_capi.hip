@@ -45,7 +45,8 @@ struct rt_ctx {
     size_t scene_bytes = 0;
     const float4 *d_filt = nullptr, *d_sph = nullptr, *d_sph_r = nullptr, *d_gen_o = nullptr, *d_gcl = nullptr, *d_refl = nullptr, *d_lpos = nullptr, *d_lcol = nullptr;
     const int32_t* d_always = nullptr;
-    const float4 *d_lfilt = nullptr, *d_lclA = nullptr, *d_lclB = nullptr, *d_sph_o = nullptr;
+    const float4 *d_lfilt = nullptr, *d_lclA = nullptr, *d_lclB = nullptr, *d_sph_o = nullptr, *d_pfilt_o = nullptr, *d_pclA = nullptr, *d_pclB = nullptr;
+    const int32_t* d_porder = nullptr;
     const int32_t *d_order = nullptr, *d_rank = nullptr;
     const int32_t *d_lalways = nullptr, *d_lalways_off = nullptr;
     const float4* d_pln = nullptr;
@@ -228,6 +229,20 @@ int32_t rt_debug_prepare_shadow_cull(const rt_objects* o, const rt_lights* l, in
     const int32_t a0 = ps.lalways_off[light], a1 = ps.lalways_off[light + 1];
     *n_always = a1 - a0;
     if (a1 > a0) std::memcpy(always, ps.lalways.data() + a0, (size_t)(a1 - a0) * sizeof(int32_t));
+    return RT_OK;
+}
+
+int32_t rt_debug_prepare_primary_cull(const rt_objects* o, int32_t* order, float* pfilt, float* cl_a, float* cl_b)
+{
+    if (!o || !order || !pfilt || !cl_a || !cl_b) return RT_ERR_INVALID;
+    const rt_lights none = {};
+    PreparedScene ps;
+    if (!prepare_scene(o, &none, ps).empty()) return RT_ERR_INVALID;
+    const size_t np = (size_t)ps.n_pad, ncl = np / kShadowCluster;
+    std::memcpy(order, ps.porder.data(), np * sizeof(int32_t));
+    std::memcpy(pfilt, ps.pfilt_o.data(), np * 16);
+    std::memcpy(cl_a, ps.pclA.data(), ncl * 16);
+    std::memcpy(cl_b, ps.pclB.data(), ncl * 16);
     return RT_OK;
 }
 
@@ -440,7 +455,11 @@ int32_t rt_scene_upload(rt_ctx* c, const rt_objects* o, const rt_lights* l)
     const size_t off_rank = off_order + np * 4;
     const size_t off_sph_o = off_rank + np * 4;
     const size_t off_gcl = off_sph_o + np * 16;
-    const size_t total = off_gcl + ncl * 16;
+    const size_t off_porder = off_gcl + ncl * 16;
+    const size_t off_pfilt = off_porder + np * 4;
+    const size_t off_pclA = off_pfilt + np * 16;
+    const size_t off_pclB = off_pclA + ncl * 16;
+    const size_t total = off_pclB + ncl * 16;
     std::vector<unsigned char> host(total, 0);
     std::memcpy(host.data() + off_filt, ps.filt.data(), np * 16);
     std::memcpy(host.data() + off_sph, ps.sph.data(), np * 16);
@@ -461,6 +480,10 @@ int32_t rt_scene_upload(rt_ctx* c, const rt_objects* o, const rt_lights* l)
     std::memcpy(host.data() + off_rank, ps.rank.data(), np * 4);
     std::memcpy(host.data() + off_sph_o, ps.sph_o.data(), np * 16);
     std::memcpy(host.data() + off_gcl, ps.gcl.data(), ncl * 16);
+    std::memcpy(host.data() + off_porder, ps.porder.data(), np * 4);
+    std::memcpy(host.data() + off_pfilt, ps.pfilt_o.data(), np * 16);
+    std::memcpy(host.data() + off_pclA, ps.pclA.data(), ncl * 16);
+    std::memcpy(host.data() + off_pclB, ps.pclB.data(), ncl * 16);
 
     RT_HIP(c, hipDeviceSynchronize());  // no render may still read the old scene (launches may sit on caller streams too)
     if (total > c->scene_bytes) {
@@ -493,6 +516,10 @@ int32_t rt_scene_upload(rt_ctx* c, const rt_objects* o, const rt_lights* l)
     c->d_rank = reinterpret_cast<const int32_t*>(base + off_rank);
     c->d_sph_o = reinterpret_cast<const float4*>(base + off_sph_o);
     c->d_gcl = reinterpret_cast<const float4*>(base + off_gcl);
+    c->d_porder = reinterpret_cast<const int32_t*>(base + off_porder);
+    c->d_pfilt_o = reinterpret_cast<const float4*>(base + off_pfilt);
+    c->d_pclA = reinterpret_cast<const float4*>(base + off_pclA);
+    c->d_pclB = reinterpret_cast<const float4*>(base + off_pclB);
     c->n_planes = (int32_t)npl;
     std::memcpy(c->ball, ps.ball, sizeof(c->ball));
     c->n = ps.n;
@@ -511,7 +538,7 @@ static int32_t check_render_args(rt_ctx* c, const float* m, uint32_t w, uint32_t
     if (depth == 0) return fail(c, RT_ERR_INVALID, "depth must be >= 1 (the reference computes depth - 1 on usize, renderer.rs:36)");
     if (w == 0 || h == 0) return fail(c, RT_ERR_INVALID, "empty frame");
     if (y0 > y1 || y1 > h) return fail(c, RT_ERR_INVALID, "row band outside the frame");
-    if (flags & ~(RT_SHADOWS | RT_OUT_RGB8 | RT_TIMED)) return fail(c, RT_ERR_INVALID, "unknown flag bits");
+    if (flags & ~(RT_SHADOWS | RT_OUT_RGB8 | RT_TIMED | RT_CULL)) return fail(c, RT_ERR_INVALID, "unknown flag bits");
     if ((uint64_t)w * (uint64_t)h > (1ull << 31)) return fail(c, RT_ERR_TOO_LARGE, "frame larger than 2^31 pixels");
     return RT_OK;
 }
@@ -579,7 +606,7 @@ static int32_t enqueue_rows(rt_ctx* c, const float m[16], uint32_t w, uint32_t h
     std::memcpy(a.m, m, sizeof(a.m));
     a.w = w; a.h = h; a.y0 = y0; a.y1 = y1; a.depth = depth; a.flags = flags;
     a.n = c->n; a.n_pad = c->n_pad; a.n_always = c->n_always; a.n_lights = c->n_lights;
-    a.filt = c->d_filt; a.sph = c->d_sph; a.sph_r = c->d_sph_r; a.gen_o = c->d_gen_o; a.gcl = c->d_gcl; a.refl = c->d_refl; a.always = c->d_always; a.lpos = c->d_lpos; a.lcol = c->d_lcol; a.lfilt = c->d_lfilt; a.lclA = c->d_lclA; a.lclB = c->d_lclB; a.order = c->d_order; a.sph_o = c->d_sph_o; a.rank = c->d_rank; a.lalways = c->d_lalways; a.lalways_off = c->d_lalways_off; a.pln = c->d_pln; a.planes = c->d_planes; a.n_planes = c->n_planes; std::memcpy(a.ball, c->ball, sizeof(a.ball));
+    a.filt = c->d_filt; a.sph = c->d_sph; a.sph_r = c->d_sph_r; a.gen_o = c->d_gen_o; a.gcl = c->d_gcl; a.refl = c->d_refl; a.always = c->d_always; a.lpos = c->d_lpos; a.lcol = c->d_lcol; a.lfilt = c->d_lfilt; a.lclA = c->d_lclA; a.lclB = c->d_lclB; a.order = c->d_order; a.sph_o = c->d_sph_o; a.rank = c->d_rank; a.lalways = c->d_lalways; a.lalways_off = c->d_lalways_off; a.porder = c->d_porder; a.pfilt_o = c->d_pfilt_o; a.pclA = c->d_pclA; a.pclB = c->d_pclB; a.pln = c->d_pln; a.planes = c->d_planes; a.n_planes = c->n_planes; std::memcpy(a.ball, c->ball, sizeof(a.ball));
     a.out = static_cast<uint8_t*>(d_out);
     a.hit_idx = static_cast<int32_t*>(d_hit_idx);
     a.rec_count = nullptr; a.rec_pix = nullptr; a.rec_idx = nullptr; a.rec_t = nullptr;

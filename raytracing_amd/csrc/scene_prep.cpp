@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <utility>
 
 namespace rtamd {
 
@@ -212,6 +213,98 @@ static void prepare_light_filters(const rt_objects* o, const rt_lights* l, Prepa
     out.lalways_off[nl] = (int32_t)out.lalways.size();
 }
 
+/*
+ * RT_CULL: the cone hierarchy of the shadow rays (above) applied to the PRIMARY rays.  All primary rays start at the origin
+ * (renderer.rs:43), so a wave's 16 x 16 pixel tile is a narrow cone of directions d, and the primary filter  f = d.c' - 1 >= 0  is the
+ * shadow filter with the "light" at the origin.  The member and cluster tests are the ones derived above with c'' = c' (the f32
+ * constants of prepare_filter, |c'| <= 4 or always open): a ray inside the cone (a, theta) can be a candidate of sphere s only if
+ * a.c' >= cos(theta) P1 - sin(theta) P2.  There is no length test (primary rays have no far end).  The filterable spheres are put in an
+ * order of their own — Morton order of the octahedral map of their direction c / |c| — so that 16 consecutive entries are neighbours ON
+ * THE SCREEN of any camera at the origin, whatever its matrix; spheres on the always-list and planes have no entry (the kernel tests
+ * them exactly for every pixel, as without RT_CULL).  Neither test drops a sphere the per-pixel filter would pass: same image by construction.
+ */
+static void prepare_primary_cull(PreparedScene& out)
+{
+    const double u = std::ldexp(1.0, -24), P1 = 1.0 - 64.0 * u;
+    const int32_t n = out.n, np = out.n_pad, ncl = np / kShadowCluster;
+    out.porder.assign(np, -1);
+    out.pfilt_o.assign(np, f4{0, 0, 0, 0});
+    out.pclA.assign(ncl, f4{0, 0, 0, 0});
+    out.pclB.assign(ncl, f4{2.0f, 0, 0, 0});  // cos = 2: an empty cluster fails every direction test
+    std::vector<std::pair<uint64_t, int32_t>> keyed;
+    auto spread = [](uint64_t v) {  // 16 bits -> every second bit
+        uint64_t r = 0;
+        for (int b = 0; b < 16; ++b) r |= ((v >> b) & 1ull) << (2 * b);
+        return r;
+    };
+    for (int32_t i = 0; i < n; ++i) {
+        if (out.cls[i] != 1) continue;
+        const f4 c = out.filt[i];
+        const double nn = std::sqrt((double)c.x * c.x + (double)c.y * c.y + (double)c.z * c.z);
+        if (!(nn > 0.0) || !std::isfinite(nn)) continue;  // (cannot happen for a filterable sphere: |c'| >= 1)
+        // octahedral map of the direction onto [0, 1]^2
+        const double l1 = std::fabs((double)c.x) + std::fabs((double)c.y) + std::fabs((double)c.z);
+        double ox = c.x / l1, oy = c.y / l1;
+        if (c.z > 0.0f) {  // fold the far hemisphere over (the default camera looks down -z: the near one stays contiguous)
+            const double fx = (1.0 - std::fabs(oy)) * (ox >= 0 ? 1.0 : -1.0), fy = (1.0 - std::fabs(ox)) * (oy >= 0 ? 1.0 : -1.0);
+            ox = fx; oy = fy;
+        }
+        auto q16 = [](double t) {
+            t = 0.5 * (t + 1.0);
+            t = t < 0 ? 0 : (t > 1 ? 1 : t);
+            return (uint64_t)(t * 65535.0);
+        };
+        keyed.emplace_back((spread(q16(ox)) | (spread(q16(oy)) << 1)) << 22 | (uint64_t)i, i);
+    }
+    std::sort(keyed.begin(), keyed.end());
+    std::vector<double> th_s(kShadowCluster), ex(kShadowCluster), ey(kShadowCluster), ez(kShadowCluster);
+    for (int32_t cl = 0; cl < ncl; ++cl) {
+        int members = 0;
+        bool open_dir = false;
+        double sx = 0, sy = 0, sz = 0;
+        for (int32_t jj = 0; jj < kShadowCluster; ++jj) {
+            const int32_t j = cl * kShadowCluster + jj;
+            if ((size_t)j >= keyed.size()) break;
+            const int32_t i = keyed[j].second;
+            f4 c = out.filt[i];
+            const double nx = c.x, ny = c.y, nz = c.z, nn = std::sqrt(nx * nx + ny * ny + nz * nz);
+            const double p2 = nn > P1 ? std::sqrt(nn * nn - P1 * P1) : 0.0;
+            c.w = std::nextafter((float)p2, INFINITY);
+            if (!(nn <= 4.0)) {  // the origin is close to the surface: theta_s > 75 deg, outside the cone argument
+                c.w = 1.0e30f;
+                open_dir = true;
+            }
+            out.porder[j] = i;
+            out.pfilt_o[j] = c;
+            th_s[members] = nn > P1 ? std::acos(P1 / nn) : 0.0;
+            ex[members] = nx / nn; ey[members] = ny / nn; ez[members] = nz / nn;
+            sx += ex[members]; sy += ey[members]; sz += ez[members];
+            ++members;
+        }
+        if (!members) continue;
+        f4 A = f4{0, 0, 0, 0}, B = f4{-2.0f, 0, 0, 0};  // cos = -2: passes every direction test
+        const double sn = std::sqrt(sx * sx + sy * sy + sz * sz);
+        if (!open_dir && sn > 1e-6) {
+            const float ax = (float)(sx / sn), ay = (float)(sy / sn), az = (float)(sz / sn);  // the axis as the kernel sees it
+            const double an = std::sqrt((double)ax * ax + (double)ay * ay + (double)az * az);
+            double th = 0.0;
+            for (int k = 0; k < members; ++k) {
+                double c = (ex[k] * ax + ey[k] * ay + ez[k] * az) / an;
+                c = c > 1.0 ? 1.0 : (c < -1.0 ? -1.0 : c);
+                th = std::fmax(th, std::acos(c) + th_s[k]);
+            }
+            th += 1e-5;
+            if (th <= 80.0 * 3.14159265358979323846 / 180.0) {
+                A.x = ax; A.y = ay; A.z = az;
+                B.x = std::nextafter((float)std::cos(th), -INFINITY);
+                B.y = std::nextafter((float)std::sin(th), INFINITY);
+            }
+        }
+        out.pclA[cl] = A;
+        out.pclB[cl] = B;
+    }
+}
+
 // Spatial order of the elements (Morton code of the sphere centres, 10 bits per axis over their bounding box; planes and non-finite
 // spheres last, in index order): out.order[j] = element at position j (-1 = padding), out.rank[i] = position of element i.
 // Consecutive positions are neighbours in space, so (i) 16 consecutive entries make a tight cluster for the shadow any-hit hierarchy
@@ -384,6 +477,7 @@ std::string prepare_scene(const rt_objects* o, const rt_lights* l, PreparedScene
         out.gcl[cl] = c;
     }
     prepare_light_filters(o, l, out);
+    prepare_primary_cull(out);
     return std::string();
 }
 

@@ -50,6 +50,11 @@ struct PreparedScene {
     std::vector<f4> lclA, lclB;        // n_lights * n_pad / 16: per cluster of 16 consecutive entries (axis x, y, z, dmin), (cos, sin of the half-angle, 0, 0)
     std::vector<int32_t> lalways;      // per light, indices of spheres its filter cannot cover (concatenated)
     std::vector<int32_t> lalways_off;  // n_lights + 1 offsets into lalways
+    // RT_CULL: the same cone hierarchy for the PRIMARY rays (common origin 0), over the primary filter's own constants, in an order of its
+    // own: the filterable spheres sorted by the DIRECTION they are seen in from the origin (scene_prep.cpp: prepare_primary_cull)
+    std::vector<int32_t> porder;       // n_pad: element at position j of that order, -1 = no entry
+    std::vector<f4> pfilt_o;           // n_pad: (cx', cy', cz', P2 of the member test) = filt in that order; all zero = no entry
+    std::vector<f4> pclA, pclB;        // n_pad / 16: per cluster of 16 consecutive positions (cone axis x, y, z, 0), (cos, sin of the half-angle, 0, 0)
 };
 
 // Returns empty string on success, else an error text. Validates kinds and pointers.

@@ -209,6 +209,78 @@ def test_shadow_hierarchy_is_conservative(oracle, seed):
     assert listed / groups < 0.25 * allo.n, "the hierarchy is a useful filter"
 
 
+@pytest.mark.parametrize("seed", [1, 2])
+def test_primary_cull_hierarchy_is_conservative(oracle, seed):
+    """RT_CULL (scene_prep.cpp: prepare_primary_cull; render_kernels.hip: tile_cone / render_cull_kernel), emulated in f32 on the CPU for
+    16 x 16 pixel tiles of several cameras: (1) every direction of a tile lies inside the cone built from its four corner directions,
+    (2) every candidate of the per-pixel filter passes the member cone test and its cluster passes the cluster cone test — so the votes
+    never drop a sphere the walk over the whole list would have tested — and (3) the order lists exactly the filterable spheres."""
+    f32 = np.float32
+    n = 400
+    objs, _ = scenegen.generate(96, 54, n, 1, seed=seed)
+    extra = np.array([[0, 0, 0, 3.0], [0, 0, -1, 1.0], [0.3, 0.2, -1.2, 0.9], [0.5, 0.5, 4, 1.0], [0.1, 0.1, -3, 1e-4], [0, 0, -500, 400.0],
+                      [3, 2, -5, 6.16], [0.02, 0.01, -1.0, 0.97]], np.float32)  # inside / on / close to the camera, behind, tiny, huge, |c'| > 4
+    cx = np.concatenate([objs.cx, extra[:, 0]]); cy = np.concatenate([objs.cy, extra[:, 1]])
+    cz = np.concatenate([objs.cz, extra[:, 2]]); rad = np.concatenate([objs.radius, extra[:, 3]])
+    one = np.ones_like(cx)
+    allo = capi.FlatObjects(cx, cy, cz, rad, one, one, one)
+    filt, cls = capi.debug_prepare_spheres(allo)
+    d = capi.debug_prepare_primary_cull(allo)
+    order, pf, cla, clb = d["order"], d["pfilt"], d["cl_a"], d["cl_b"]
+    assert sorted(order[order >= 0]) == sorted(np.nonzero(cls == 1)[0].tolist())
+    entry = (pf[:, :3] != 0).any(1)
+    assert np.array_equal(entry, order >= 0)
+    assert np.array_equal(pf[entry, :3], filt[order[entry], :3])  # the very constants the default path filters with
+    assert (np.linalg.norm(pf[entry, :3].astype(np.float64), axis=1) > 4).any(), "the always-open member branch is exercised"
+    P1 = f32(1.0) - f32(3.814697265625e-06)
+    rng = np.random.default_rng(40 + seed)
+    cams = [(1920, 1080, None), (3840, 2160, None), (100, 100, None), (333, 77, None)]
+    g = (rng.standard_normal(16) * 0.7).astype(f32); g[10] -= f32(1.5)
+    cams.append((640, 360, g))
+    cand_total = listed = tiles = wides = 0
+    for (w, h, m) in cams:
+        m = oracle.default_camera(w, h) if m is None else m
+        for _ in range(10):
+            x0 = int(rng.integers(0, (w + 15) // 16)) * 16
+            y0 = int(rng.integers(0, (h + 15) // 16)) * 16
+            xs = np.minimum(x0 + np.arange(16), w - 1)   # the kernel clamps pixels beyond the frame's edge
+            ys = np.minimum(y0 + np.arange(16), h - 1)
+            dirs = np.array([[oracle.unit3(oracle.pixel_position(m, int(x), int(y), w, h)) for x in xs] for y in ys], f32)  # [row, col, 3]
+            corners = np.stack([dirs[0, 0], dirs[0, 15], dirs[15, 0], dirs[15, 15]])
+            # tile_cone as the kernel evaluates it
+            a = ((corners[0] + corners[1]).astype(f32) + (corners[2] + corners[3]).astype(f32)).astype(f32)
+            an = np.sqrt((a * a).sum(dtype=f32), dtype=f32)
+            a = (a / an).astype(f32)
+            c = (corners * a).sum(1, dtype=f32)
+            cr = np.cross(a.astype(np.float64), corners.astype(np.float64)).astype(f32)
+            smax = f32(np.sqrt((cr * cr).sum(1, dtype=f32), dtype=f32).max())
+            wide = not (np.isfinite(corners).all() and an > 0 and np.isfinite(an) and c.min() > 0.5)
+            sinT = f32(smax * f32(1.0 + 1.0e-6) + f32(4.0e-6))
+            cosT = f32(np.sqrt(max(f32(0), f32(1.0) - sinT * sinT), dtype=f32) * f32(1.0 - 1.0e-6))
+            flat = dirs.reshape(-1, 3)
+            if not wide:  # (1) in float64: the sine of the angle between the axis and every direction of the tile
+                s64 = np.linalg.norm(np.cross(a.astype(np.float64), flat.astype(np.float64)), axis=1) / np.linalg.norm(flat.astype(np.float64), axis=1)
+                assert (s64 <= float(smax) * (1 + 1e-6) + 2.0e-6).all(), "a direction of the tile lies outside the corner cone"
+            # (2) per-pixel filter candidates over all positions, member and cluster votes as the kernel evaluates them
+            fv = _fma32(flat[:, 0:1], pf[None, :, 0], _fma32(flat[:, 1:2], pf[None, :, 1], _fma32(flat[:, 2:3], pf[None, :, 2], f32(-1.0))))
+            cand = (fv >= 0) & entry[None, :]
+            mdot = _fma32(a[0], pf[:, 0], _fma32(a[1], pf[:, 1], f32(a[2] * pf[:, 2])))
+            mrhs = _fma32(cosT, P1, -(sinT * pf[:, 3]).astype(f32))
+            mpass = entry & (wide | (mdot >= mrhs - f32(8.0e-6)))
+            cdot = _fma32(a[0], cla[:, 0], _fma32(a[1], cla[:, 1], f32(a[2] * cla[:, 2])))
+            crhs = _fma32(cosT, clb[:, 0], -(sinT * clb[:, 1]).astype(f32))
+            cdir = wide | (cdot >= crhs - f32(4.0e-6))
+            _, pos = np.nonzero(cand)
+            cand_total += len(pos)
+            assert mpass[pos].all(), "a filter candidate failed the member cone test"
+            assert cdir[pos // 16].all(), "the cluster of a filter candidate failed the cluster cone test"
+            listed += int((mpass & np.repeat(cdir, 16)).sum())
+            tiles += 1
+            wides += int(wide)
+    assert cand_total > 300 and wides < tiles // 4
+    assert listed / tiles < 0.1 * allo.n, "the hierarchy is a useful filter"
+
+
 def test_scenegen_is_deterministic_and_pinned():
     o1, l1 = scenegen.generate(3840, 2160, 1024, 4)
     o2, l2 = scenegen.generate(3840, 2160, 1024, 4)

@@ -378,6 +378,9 @@ def test_fuzz_scenes_cameras_modes(gpu_ctx, oracle):
         ref, ref_hit = oracle.render(objs, lights, m, w, h, depth=depth, flags=flags & 1, channels=3 if flags & 2 else 4, want_hit_idx=True)
         _assert_same(gpu, ref, f"fuzz case {case}: {w}x{h} n={n} l={nl} depth={depth} flags={flags}")
         assert np.array_equal(hit, ref_hit), f"fuzz case {case}: hit index plane"
+        gpu, hit = gpu_ctx.render_rows(m, w, h, 0, h, depth, flags | capi.RT_CULL, want_hit_idx=True)  # primary rays through the cone hierarchy
+        _assert_same(gpu, ref, f"fuzz case {case} with RT_CULL: {w}x{h} n={n} l={nl} depth={depth} flags={flags}")
+        assert np.array_equal(hit, ref_hit), f"fuzz case {case} with RT_CULL: hit index plane"
         npix += w * h
         nlit += int((hit >= 0).sum())
     print(f"fuzz: {case + 1} scenes, {npix} pixels compared, {nlit} with a hit")
@@ -432,6 +435,9 @@ def test_shadow_hierarchy_fuzz(gpu_ctx, oracle):
         ref, ref_hit = oracle.render(objs, lights, m, w, h, depth=depth, flags=1, channels=3 if flags & 2 else 4, want_hit_idx=True)
         _assert_same(gpu, ref, f"shadow fuzz case {case}: {w}x{h} n={objs.n} l={nl} depth={depth}")
         assert np.array_equal(hit, ref_hit)
+        gpu_c, hit_c = gpu_ctx.render_rows(m, w, h, 0, h, depth, flags | capi.RT_CULL, want_hit_idx=True)
+        _assert_same(gpu_c, ref, f"shadow fuzz case {case} with RT_CULL")
+        assert np.array_equal(hit_c, ref_hit)
         lit = gpu_ctx.render_rows(m, w, h, 0, h, depth, flags & ~capi.RT_SHADOWS)[0]
         nrec += int((hit >= 0).sum())
         if depth == 1:
@@ -481,9 +487,119 @@ def test_bounce_hierarchy_fuzz(gpu_ctx, oracle):
         ref, ref_hit = oracle.render(objs, lights, m, w, h, depth=depth, flags=flags & 1, channels=3 if flags & 2 else 4, want_hit_idx=True)
         _assert_same(gpu, ref, f"bounce fuzz case {case}: {w}x{h} n={objs.n} depth={depth} flags={flags}")
         assert np.array_equal(hit, ref_hit)
+        gpu_c, hit_c = gpu_ctx.render_rows(m, w, h, 0, h, depth, flags | capi.RT_CULL, want_hit_idx=True)
+        _assert_same(gpu_c, ref, f"bounce fuzz case {case} with RT_CULL")
+        assert np.array_equal(hit_c, ref_hit)
         nrec += int((hit >= 0).sum())
     assert nrec > 150000
     print(f"bounce fuzz: {case + 1} scenes, {nrec} hit records")
+
+
+def test_cull_default_scene_edges_and_bands(gpu_ctx, oracle):
+    """RT_CULL (primary rays through the cone hierarchy, render_cull_kernel) gives the bytes of the reference path: C1 against the
+    reference's result.png, C2 on every pixel, ragged frame sizes (tiles cut by the right and bottom edges, frames smaller than a tile),
+    row bands that start inside a tile row, RGB8, spheres around / on / behind the camera (always-list), planes, empty scenes."""
+    gold = np.load(os.path.join(GOLDEN, "result_100x100.npy"))
+    objs, lights = _default_flat()
+    gpu_ctx.scene_upload(objs, lights)
+    m = capi.camera_transform(*capi.camera_default(), np.float32(1.0))
+    _assert_same(gpu_ctx.render(m, 100, 100, 1, capi.RT_CULL)[..., :3], gold, "C1 RT_CULL")
+    _assert_same(gpu_ctx.render(m, 100, 100, 1, capi.RT_CULL | capi.RT_OUT_RGB8), gold, "C1 RT_CULL RGB8")
+    m = _cam(oracle, 1920, 1080)
+    gpu, hit = gpu_ctx.render_rows(m, 1920, 1080, 0, 1080, 1, capi.RT_CULL, want_hit_idx=True)
+    ref, ref_hit = oracle.render(objs, lights, m, 1920, 1080, want_hit_idx=True)
+    _assert_same(gpu, ref, "C2 RT_CULL")
+    assert np.array_equal(hit, ref_hit)
+    for (w, h, n, l, seed) in [(257, 131, 37, 3, 1), (64, 64, 1, 1, 2), (333, 77, 300, 5, 3), (16, 4, 16, 2, 4), (1, 1, 5, 1, 5), (640, 360, 1500, 4, 6),
+                               (65, 17, 90, 2, 7), (15, 33, 20, 1, 8)]:
+        o, li = scenegen.generate(w, h, n, l, seed=seed)
+        gpu_ctx.scene_upload(o, li)
+        m = _cam(oracle, w, h)
+        ref, ref_hit = oracle.render(o, li, m, w, h, want_hit_idx=True)
+        gpu, hit = gpu_ctx.render_rows(m, w, h, 0, h, 1, capi.RT_CULL, want_hit_idx=True)
+        _assert_same(gpu, ref, f"RT_CULL {w}x{h} n={n}")
+        assert np.array_equal(hit, ref_hit)
+        if h > 20:  # bands whose first row is not a multiple of the tile height
+            for y0, y1 in ((3, h - 5), (h // 2 + 1, h), (7, 8)):
+                band, bhit = gpu_ctx.render_rows(m, w, h, y0, y1, 1, capi.RT_CULL | capi.RT_OUT_RGB8, want_hit_idx=True)
+                _assert_same(band, ref[y0:y1, :, :3], f"RT_CULL band {y0}:{y1} of {w}x{h}")
+                assert np.array_equal(bhit, ref_hit[y0:y1])
+    # camera inside / on / next to spheres, duplicates, a sphere behind the camera, a huge far one; two planes
+    f = np.float32
+    c = np.array([[0, 0, 0, 3.0], [0, 0, -1, 1.0], [0.2, 0.1, -1, 0.99999], [0.5, 0.5, 4, 1.0], [0.1, 0.1, -3, 1e-4], [0, 0, -500, 400.0],
+                  [1, 0.5, -4, 0.7], [1, 0.5, -4, 0.7], [-2, -1, -6, 1.1], [3, 2, -5, 6.16]], f)
+    one = np.ones(len(c), f)
+    for drop_first in (False, True):
+        cc = c[1:] if drop_first else c
+        o = capi.FlatObjects(cc[:, 0], cc[:, 1], cc[:, 2], cc[:, 3], one[: len(cc)] * f(0.9), one[: len(cc)] * f(0.5), one[: len(cc)] * f(0.7))
+        o = _with_planes(o, [((0.0, -2.0, 0.0), (0.0, 1.0, 0.02), (0.5, 0.6, 0.7))])
+        li = capi.FlatLights(f([1, -4]), f([2, 1]), f([0, -3]), f([1, 0.3]), f([1, 0.3]), f([1, 0.3]), f([6, 9]), kind=np.array([0, 1], np.uint8))
+        gpu_ctx.scene_upload(o, li)
+        m = _cam(oracle, 200, 120)
+        for depth, sh in ((1, 0), (2, 0), (2, capi.RT_SHADOWS)):
+            ref, ref_hit = oracle.render(o, li, m, 200, 120, depth=depth, flags=sh, want_hit_idx=True)
+            gpu, hit = gpu_ctx.render_rows(m, 200, 120, 0, 120, depth, sh | capi.RT_CULL, want_hit_idx=True)
+            _assert_same(gpu, ref, f"RT_CULL awkward spheres depth={depth} shadows={sh} drop_first={drop_first}")
+            assert np.array_equal(hit, ref_hit)
+    z = np.zeros(0, f)
+    gpu_ctx.scene_upload(capi.FlatObjects(z, z, z, z, z, z, z), capi.FlatLights(z, z, z, z, z, z, z))
+    assert not gpu_ctx.render(_cam(oracle, 50, 30), 50, 30, 1, capi.RT_CULL)[..., :3].any()
+    assert not gpu_ctx.render(_cam(oracle, 50, 30), 50, 30, 2, capi.RT_CULL | capi.RT_SHADOWS)[..., :3].any()
+
+
+@pytest.mark.parametrize("cfg", ["C3", "C5", "C4"])
+def test_cull_full_size_equals_the_default_path(gpu_ctx, oracle, cfg):
+    """RT_CULL at the BASELINE sizes: the WHOLE frame and hit plane byte-equal to the default launch (which the tests above hold to the
+    oracle on sampled rows), sampled rows against the oracle directly, and for C3 / C5 also depth 2 and RT_SHADOWS (the hit records the
+    culled emit kernel appends feed the same general-ray kernels)."""
+    import torch
+    w, h, objs, lights = scenegen.config(cfg)
+    gpu_ctx.scene_upload(objs, lights)
+    m = _cam(oracle, w, h)
+    modes = [(1, 0)] if cfg == "C4" else [(1, 0), (2, 0), (1, capi.RT_SHADOWS)]
+    out = [torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda") for _ in range(2)]
+    hit = [torch.full((h, w), -7, dtype=torch.int32, device="cuda") for _ in range(2)]
+    for depth, sh in modes:
+        for k, fl in enumerate((sh, sh | capi.RT_CULL)):
+            gpu_ctx.render_rows_device(m, w, h, 0, h, depth, fl, out[k].data_ptr(), hit[k].data_ptr())
+        torch.cuda.synchronize()
+        assert torch.equal(out[0], out[1]), f"{cfg} depth={depth} shadows={sh}: RT_CULL frame differs in {int((out[0] != out[1]).any(dim=-1).sum())} pixels"
+        assert torch.equal(hit[0], hit[1])
+        assert int((hit[1] >= 0).sum()) > w * h // 20
+    step = {"C3": 90, "C5": 216, "C4": 1080}[cfg]
+    rows = list(range(7, h, step))
+    ref = oracle.render(objs, lights, m, w, h, row_step=1, y0=0, y1=1)  # row 0
+    gpu_ctx.render_rows_device(m, w, h, 0, h, 1, capi.RT_CULL, out[1].data_ptr(), hit[1].data_ptr())
+    torch.cuda.synchronize()
+    got = out[1].cpu().numpy()
+    _assert_same(got[0:1], ref, f"{cfg} RT_CULL row 0")
+    for y in rows:
+        _assert_same(got[y:y + 1], oracle.render(objs, lights, m, w, h, y0=y, y1=y + 1), f"{cfg} RT_CULL row {y}")
+
+
+def test_cull_through_bands_and_the_noalloc_entry_point(oracle):
+    """RT_CULL through a multi-device context (virtual bands, gathered by RCCL) and through rt_render_rows_device_noalloc: same bytes as
+    the single default launch."""
+    import torch
+    w, h = 1280, 720
+    objs, lights = scenegen.generate(w, h, 600, 3, seed=12)
+    m = _cam(oracle, w, h)
+    with capi.Context(0) as one:
+        one.scene_upload(objs, lights)
+        ref = one.render(m, w, h, 1)
+        ref2 = one.render(m, w, h, 2, capi.RT_SHADOWS)
+        out = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+        one.render_rows_device_noalloc(m, w, h, 0, h, 1, capi.RT_CULL, out.data_ptr())
+        torch.cuda.synchronize()
+        _assert_same(out.cpu().numpy(), ref, "RT_CULL noalloc")
+        half = torch.zeros((200, w, 4), dtype=torch.uint8, device="cuda")
+        one.render_rows_device_noalloc(m, w, h, 100, 300, 2, capi.RT_CULL | capi.RT_SHADOWS, half.data_ptr())
+        torch.cuda.synchronize()
+        _assert_same(half.cpu().numpy(), ref2[100:300], "RT_CULL noalloc general band")
+    with capi.Context(device_ids=[0, 0, 0]) as multi:
+        multi.scene_upload(objs, lights)
+        _assert_same(multi.render(m, w, h, 1, capi.RT_CULL), ref, "RT_CULL 3 virtual bands")
+        _assert_same(multi.render(m, w, h, 2, capi.RT_CULL | capi.RT_SHADOWS), ref2, "RT_CULL 3 virtual bands, general path")
 
 
 def test_wavefront_many_lights_depth_and_bands(gpu_ctx, oracle):

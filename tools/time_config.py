@@ -11,6 +11,7 @@ ap.add_argument("--shadows", action="store_true")
 ap.add_argument("--depth", type=int, default=1)
 ap.add_argument("--frames", type=int, default=5)
 ap.add_argument("--rows", default=None)
+ap.add_argument("--cull", action="store_true", help="RT_CULL: primary rays through the cone hierarchy")
 ap.add_argument("--rgb8", action="store_true", help="RT_OUT_RGB8: 3 B/pixel, the layout of Framebuffer.pixels")
 a = ap.parse_args()
 w, h, objs, lights = scenegen.config(a.config)
@@ -18,7 +19,7 @@ y0, y1 = (0, h) if a.rows is None else map(int, a.rows.split(":"))
 m = capi.camera_transform(*capi.camera_default(), np.float32(w) / np.float32(h))
 import torch
 out = torch.zeros(((y1 - y0), w, 4), dtype=torch.uint8, device="cuda")
-flags = (capi.RT_SHADOWS if a.shadows else 0) | (capi.RT_OUT_RGB8 if a.rgb8 else 0) | capi.RT_TIMED
+flags = (capi.RT_SHADOWS if a.shadows else 0) | (capi.RT_OUT_RGB8 if a.rgb8 else 0) | (capi.RT_CULL if a.cull else 0) | capi.RT_TIMED
 with capi.Context(0) as ctx:
     ctx.scene_upload(objs, lights)
     import time
