@@ -6,7 +6,7 @@ A step = one pass of the hot path over one frame: every rank renders its row ban
 torch.distributed "nccl", double-buffered so the gather of frame k overlaps the render of frame k+1); with --gpus 1 no
 collective is issued.  Total work per step is fixed (one frame) => strong scaling.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3|C4|C5] [--depth D] [--shadows] [--no-cpu-baseline]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C3|C4|C5] [--depth D] [--shadows] [--cull] [--no-cpu-baseline]
   N > 1:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line (metric/value/roofline/cpu_baseline ...).  The oracle is used only for the cpu_baseline leg.
@@ -22,6 +22,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_VALU_TFLOPS = 157.3  # MI355X_MICROARCH.md: 256 CU x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+PEAK_HBM_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E ~8 TB/s
 FLOPS_PER_TEST = 6             # the hot loop executes three v_fma_f32 per (pixel, sphere) pair (render_kernels.h)
 FLOPS_PER_SHADOW_TEST = 6      # shadow_mask_kernel: the same 3-FMA filter per (shadow ray, sphere) with per-light constants
 FLOPS_PER_BOUNCE_TEST = 14     # trace_bundle's filter: 7 FMAs per (bounce ray, sphere) it tests (round 2 walked the whole list with 10 operations, 16 flops)
@@ -35,6 +36,7 @@ def main():
     ap.add_argument("--config", default="C3", choices=["C3", "C4", "C5"])
     ap.add_argument("--depth", type=int, default=1, help="renderer.rs:32 depth; > 1 runs the bounce path (general-ray kernels)")
     ap.add_argument("--shadows", action="store_true", help="RT_SHADOWS extension (general-ray kernels)")
+    ap.add_argument("--cull", action="store_true", help="RT_CULL (opt-in, same bytes out): primary rays through the cone hierarchy instead of the walk over the whole list")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     if args.depth < 1:
@@ -110,7 +112,7 @@ def main():
     # three frame times before it holds up its slot (its kernel only gets workgroup slots as render workgroups leave).  The streams
     # are probed for real concurrency (pick_concurrent_streams): as many slots as mutually concurrent streams, at most four.
     general = args.depth > 1 or args.shadows
-    flags = capi.RT_SHADOWS if args.shadows else 0
+    flags = (capi.RT_SHADOWS if args.shadows else 0) | (capi.RT_CULL if args.cull else 0)
     slots = int(os.environ.get("BENCH_SLOTS", "4")) if use_dist else 1
     if general:
         slots = min(slots, 2)  # general launches of one context are ordered by the library (shared hit records): two slots overlap the gather only
@@ -330,13 +332,26 @@ def main():
         my_tests = (y1 - y0) * w * objs.n
         kernels = [("render_kernel<primary>" if not general else "render_kernel<emit>", my_tests, FLOPS_PER_TEST, kern_ms if not general else phase_ms[0],
                     "%d per (pixel,sphere) filter test x %d tests per launch" % (FLOPS_PER_TEST, my_tests))]
+        cull_info = None
+        if args.cull:
+            # render_cull_kernel: the cone hierarchy tests only the spheres a tile's rays can reach, so the work is data-dependent: executed
+            # flops = the counter-derived figure of the committed PMC pass of this command (None without one), beside the whole-list bound
+            cname = "render_cull_kernel<primary>" if not general else "render_cull_kernel<emit>"
+            pv, pnote = pmc_summary(args.config, args.depth, args.shadows, cname, cull=True)
+            cu_flops = pv.get("flops") if pv else None
+            bound = FLOPS_PER_TEST * my_tests
+            cull_info = {"whole_list_bound_flops": bound, "executed_flops": cu_flops, "executed_over_bound": (cu_flops / bound) if cu_flops else None,
+                         "lane_utilisation": pv.get("lane_utilisation") if pv else None, "source": ("counter-derived flops " + pnote) if cu_flops else pnote}
+            kernels = [(cname, 1, cu_flops or 0.0, kern_ms if not general else phase_ms[0],
+                        ("counter-derived: %.4g flops per launch, %.4f of the whole-list bound (%d per (pixel,sphere) filter test x %d tests)" % (cu_flops, cu_flops / bound, FLOPS_PER_TEST, my_tests))
+                        if cu_flops else "executed flops unknown (%s); whole-list bound %.4g" % (pnote, bound))]
         shadow_info = None
         if general and args.shadows:
             # shadow_mask_kernel: its any-hit hierarchy tests only the spheres a wave's rays can reach, so the work is data-dependent:
             # the executed flops are the counter-derived figure of the committed PMC pass of this command (None without one); the
             # no-early-out bound (every shadow ray against every sphere with the 3-FMA filter) is reported beside it
             bound = FLOPS_PER_SHADOW_TEST * n_hits * n_point * objs.n * args.depth
-            pv, pnote = pmc_summary(args.config, args.depth, True, "shadow_mask_kernel")
+            pv, pnote = pmc_summary(args.config, args.depth, True, "shadow_mask_kernel", cull=args.cull)
             sh_flops = pv.get("flops") if pv else None
             if sh_flops:
                 sh_flops *= args.depth  # the summary averages the launches of one frame: one per iteration of renderer.rs:46
@@ -355,7 +370,7 @@ def main():
             # can reach: executed flops = the counter-derived figure of the committed PMC pass of this command (None without one), beside
             # the bound of walking the whole list with the 7-FMA filter for every bounce ray
             bound = FLOPS_PER_BOUNCE_TEST * n_hits * objs.n * (args.depth - 1)
-            pv, pnote = pmc_summary(args.config, args.depth, args.shadows, "shade_iter_kernel")
+            pv, pnote = pmc_summary(args.config, args.depth, args.shadows, "shade_iter_kernel", cull=args.cull)
             bo_flops = pv.get("flops") if pv else None
             if bo_flops:
                 bo_flops *= args.depth  # the summary averages the launches of one frame: one per iteration of renderer.rs:46
@@ -380,7 +395,9 @@ def main():
         metric = {"C3": "primary rays/sec at 4K, 1024 spheres (config C3)",
                   "C4": "primary rays/sec at 8K, 8192 spheres (config C4)",
                   "C5": "primary rays/sec at 4K, 4096 spheres, 32 lights (config C5)"}[args.config]
-        if general:
+        if args.cull:
+            mode += ", RT_CULL (opt-in: primary rays through the cone hierarchy)"
+        if general or args.cull:
             metric = metric.replace("primary rays/sec", "primary rays/sec [%s]" % mode)
         out = {
             "metric": metric,
@@ -414,7 +431,18 @@ def main():
                                    "shadow_any_hit": shadow_info, "bounce_closest_hit": bounce_info,
                                    "rays_per_step": w * h + (n_hits * n_point * args.depth if args.shadows else 0) + n_hits * (args.depth - 1),
                                    "note": "value counts primary rays only; rays_per_step adds the shadow and bounce rays (upper bounds: later iterations hold fewer live records)"}
-        out["roofline"]["traffic"], out["roofline"]["traffic_note"] = pmc_traffic(args.config, args.depth, args.shadows, dom[0])
+        out["roofline"]["traffic"], out["roofline"]["traffic_note"] = pmc_traffic(args.config, args.depth, args.shadows, dom[0], cull=args.cull)
+        if args.cull:
+            out["cull"] = cull_info
+            if not general and not wall_based:
+                # no FLOP roofline applies to the culled walk (it executes ~1 % of the whole-list flops): the line reports the frame write
+                # against HBM — the only algorithmic bytes of the launch — and the executed flops beside it; what bounds the kernel is
+                # VALU issue of the per-pixel ray setup in the reference's exact arithmetic (IEEE divisions and square roots)
+                gbps = (y1 - y0) * w * 4 / (dom_ms * 1e-3) / 1e9
+                out["roofline"].update({"bound": "hbm", "achieved": gbps, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": gbps / PEAK_HBM_GBPS,
+                                        "flops_counted": "algorithmic bytes = the RGBA8 frame write, %d B per launch; %s" % ((y1 - y0) * w * 4, dom[4]),
+                                        "valu_TFLOP/s_executed": (cu_flops / (dom_ms * 1e-3) / 1e12) if cu_flops else None,
+                                        "note": "neither roofline binds: VALU issue of the exact per-pixel ray setup does (DESIGN.md 3.5)"})
         if diag is not None:
             out["diagnostics"] = diag
         if backend == "gloo" and use_dist:
@@ -499,17 +527,18 @@ def kernel_source_sha256():
     return hsh.hexdigest()
 
 
-def pmc_summary(config, depth=1, shadows=False, kernel="render_kernel<primary>"):
+def pmc_summary(config, depth=1, shadows=False, kernel="render_kernel<primary>", cull=False):
     """Figures of the committed rocprofv3 PMC passes of THIS command for one kernel (profiles/r03_<tag>_pmc.txt, written by
     tools/summarize_prof.py): HBM bytes per launch (TCC_EA0_WRREQ x 64 B + TCC_EA0_RDREQ x 64 B x 2, the gfx950 correction of
     MI355X_MICROARCH.md) and the counter-derived f32 flops per launch.  Counters cannot be read inside an unprofiled run, so these are
     the values of the profiled run of the same command — and only if the summary was taken with the kernel sources this build comes
     from (its `kernel source sha256` line).  Returns (dict or None, note)."""
-    tag = config.lower() + ("_depth%d" % depth if depth > 1 else "") + ("_shadows" if shadows else "")
+    tag = config.lower() + ("_depth%d" % depth if depth > 1 else "") + ("_shadows" if shadows else "") + ("_cull" if cull else "")
     path = os.path.join(ROOT, "profiles", "r03_%s_pmc.txt" % tag)
     if not os.path.exists(path):
         return None, "no PMC pass committed for this command (%s)" % os.path.basename(path)
-    want = "render_kernel<16, false>" if kernel == "render_kernel<primary>" else ("render_kernel<16, true>" if kernel == "render_kernel<emit>" else kernel.split(" ")[0])
+    want = {"render_kernel<primary>": "render_kernel<16, false>", "render_kernel<emit>": "render_kernel<16, true>",
+            "render_cull_kernel<primary>": "render_cull_kernel<false", "render_cull_kernel<emit>": "render_cull_kernel<true"}.get(kernel, kernel.split(" ")[0])
     sha = None
     vals = {}
     inside = False
@@ -533,8 +562,8 @@ def pmc_summary(config, depth=1, shadows=False, kernel="render_kernel<primary>")
     return vals, "per launch of %s, from %s (separate --pmc passes of this command, same kernel sources)" % (want, os.path.relpath(path, ROOT))
 
 
-def pmc_traffic(config, depth=1, shadows=False, kernel="render_kernel<primary>"):
-    vals, note = pmc_summary(config, depth, shadows, kernel)
+def pmc_traffic(config, depth=1, shadows=False, kernel="render_kernel<primary>", cull=False):
+    vals, note = pmc_summary(config, depth, shadows, kernel, cull)
     return (vals["wr"] + vals["rd"], "bytes " + note) if vals else (None, note)
 
 

@@ -650,10 +650,14 @@ __device__ __forceinline__ bool tile_cone(const float (&dx)[P], const float (&dy
 // is immaterial.  Neither vote drops a sphere the per-pixel filter would pass.  Spheres on the always-list and planes are tested
 // exactly for every pixel, as in render_tile.  A plain grid, one tile (4 waves side by side: 64 x 16 pixels) per workgroup: tiles are
 // microseconds long, a queue would be bound by its atomic.  No workgroup barrier: the waves are independent.
+#ifndef RT_CULL_P
+#define RT_CULL_P 4
+#endif
+constexpr int kCullP = RT_CULL_P;  // pixels per lane (one column, kLY rows apart) of render_cull_kernel: a wave's tile is 16 x (4 * kCullP) pixels
 template <bool EMIT, int CAP>
 __global__ __launch_bounds__(kWaves * 64) void render_cull_kernel(const RenderArgs A)
 {
-    constexpr int P = 4, B = 8;
+    constexpr int P = kCullP, B = 8;
     static_assert(CAP % B == 0 && CAP >= 128, "list geometry");
     __shared__ float4 s_list[kWaves][CAP];  // per wave: (c'x, c'y, c'z, element index as bits)
     __shared__ int s_open[kWaves][256];     // per wave: the clusters the current vote opened
@@ -664,7 +668,7 @@ __global__ __launch_bounds__(kWaves * 64) void render_cull_kernel(const RenderAr
     int* const s_cl = s_open[wave];
     const uint32_t t = blockIdx.x;
     const uint32_t x_base = (t % A.strips) * (kWaves * kLX) + (uint32_t)(wave * kLX + (lane & (kLX - 1)));
-    const uint32_t y_base = A.y0 + (t / A.strips) * (4 * kLY) + (uint32_t)(lane >> 4);
+    const uint32_t y_base = A.y0 + (t / A.strips) * (P * kLY) + (uint32_t)(lane >> 4);
     if ((t % A.strips) * (kWaves * kLX) + (uint32_t)(wave * kLX) >= A.w) return;  // (wave-uniform) this wave's 16 columns lie beyond the frame
 
     float dx[P], dy[P], dz[P], best_t[P];
@@ -1521,7 +1525,7 @@ hipError_t launch_primary_cull(RenderArgs a, hipStream_t stream)
 {
     if (!a.pfilt_o || !a.porder || !a.pclA || !a.pclB) return hipErrorInvalidValue;
     a.strips = (a.w + kWaves * kLX - 1) / (kWaves * kLX);
-    const uint64_t n_tiles = (uint64_t)a.strips * ((a.y1 - a.y0 + 4 * kLY - 1) / (4 * kLY));
+    const uint64_t n_tiles = (uint64_t)a.strips * ((a.y1 - a.y0 + kCullP * kLY - 1) / (kCullP * kLY));
     if (n_tiles >= (1ull << 31)) return hipErrorInvalidValue;
     hipLaunchKernelGGL((render_cull_kernel<EMIT, kCullCap>), dim3((uint32_t)n_tiles), dim3(kWaves * 64), 0, stream, a);
     return hipGetLastError();

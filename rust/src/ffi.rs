@@ -10,6 +10,7 @@ pub const RT_AMBIENT: u8 = 1;
 pub const RT_SHADOWS: u32 = 1;
 pub const RT_OUT_RGB8: u32 = 2;
 pub const RT_TIMED: u32 = 4; // rt_render_rows_device: record the events rt_last_kernel_ms / rt_last_phase_ms read
+pub const RT_CULL: u32 = 8; // opt-in, same bytes out: primary rays through the cone hierarchy instead of the walk over the whole list
 
 #[repr(C)]
 pub struct rt_objects {

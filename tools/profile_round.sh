@@ -21,3 +21,8 @@ one c3_depth2 --config C3 --depth 2
 one c5_shadows --config C5 --shadows
 one c5 --config C5
 one c4 --config C4
+one c3_cull --config C3 --cull
+one c3_depth2_cull --config C3 --depth 2 --cull
+one c5_shadows_cull --config C5 --shadows --cull
+one c4_cull --config C4 --cull
+one c5_cull --config C5 --cull
