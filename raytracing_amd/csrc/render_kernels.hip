@@ -212,9 +212,13 @@ __device__ __forceinline__ void store_pixel(const RenderArgs& A, size_t pix, flo
 // The end of a tile, given every pixel's closest hit: EMIT = false: shade (depth 1, no shadows) and store the pixel — the whole reference
 // path.  EMIT = true: store black, and append every hit as a record (pixel, element, t) to a dense list for the general-ray kernels
 // below (bounces / shadow rays then run with full lanes instead of the frame's ~20 % coverage).
+// `s_agg` (EMIT only; null = one atomic per wave): kWaves + 1 words of LDS through which the four waves of the workgroup reserve their
+// records with ONE atomic (two workgroup barriers: every wave of the workgroup must arrive here) — returning atomics on one address
+// complete at only ~40-80 M/s chip-wide, which bounds a kernel whose tiles take microseconds (render_cull_kernel).
 template <int P, bool EMIT>
 __device__ __forceinline__ void finish_tile(const RenderArgs& A, int lane, uint32_t inb, uint32_t x_base, uint32_t y_base, const float (&dx)[P],
-                                            const float (&dy)[P], const float (&dz)[P], const float (&best_t)[P], const int (&best_i)[P])
+                                            const float (&dy)[P], const float (&dz)[P], const float (&best_t)[P], const int (&best_i)[P],
+                                            uint32_t* s_agg = nullptr)
 {
     if (!EMIT) {
         // ---- shading and store (depth 1, reference semantics) ----
@@ -241,7 +245,21 @@ __device__ __forceinline__ void finish_tile(const RenderArgs& A, int lane, uint3
             total += (uint32_t)__builtin_popcountll(hitmask[p]);
         }
         uint32_t base = 0;
-        if (lane == 0 && total) base = atomicAdd(A.rec_count, total);
+        if (s_agg) {
+            const int wave = threadIdx.x >> 6;
+            if (lane == 0) s_agg[wave] = total;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t sum = 0;
+                for (int i = 0; i < kWaves; ++i) sum += s_agg[i];
+                s_agg[kWaves] = sum ? atomicAdd(A.rec_count, sum) : 0u;
+            }
+            __syncthreads();
+            base = s_agg[kWaves];
+            for (int i = 0; i < wave; ++i) base += s_agg[i];
+        } else if (lane == 0 && total) {
+            base = atomicAdd(A.rec_count, total);
+        }
         base = __builtin_amdgcn_readfirstlane(base);
         uint32_t off = base;
 #pragma unroll
@@ -649,7 +667,7 @@ __device__ __forceinline__ bool tile_cone(const float (&dx)[P], const float (&dy
 // wave vote -> the reference's exact test for candidates -> closest hit as the lexicographic minimum of (t, index), so the list order
 // is immaterial.  Neither vote drops a sphere the per-pixel filter would pass.  Spheres on the always-list and planes are tested
 // exactly for every pixel, as in render_tile.  A plain grid, one tile (4 waves side by side: 64 x 16 pixels) per workgroup: tiles are
-// microseconds long, a queue would be bound by its atomic.  No workgroup barrier: the waves are independent.
+// microseconds long, a queue would be bound by its atomic.  The waves are independent (no barrier) until they reserve their hit records.
 #ifndef RT_CULL_P
 #define RT_CULL_P 4
 #endif
@@ -661,6 +679,7 @@ __global__ __launch_bounds__(kWaves * 64) void render_cull_kernel(const RenderAr
     static_assert(CAP % B == 0 && CAP >= 128, "list geometry");
     __shared__ float4 s_list[kWaves][CAP];  // per wave: (c'x, c'y, c'z, element index as bits)
     __shared__ int s_open[kWaves][256];     // per wave: the clusters the current vote opened
+    __shared__ uint32_t s_agg[kWaves + 1];  // EMIT: the workgroup's record reservation (finish_tile)
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
     const int lane = tid & 63;
@@ -669,7 +688,8 @@ __global__ __launch_bounds__(kWaves * 64) void render_cull_kernel(const RenderAr
     const uint32_t t = blockIdx.x;
     const uint32_t x_base = (t % A.strips) * (kWaves * kLX) + (uint32_t)(wave * kLX + (lane & (kLX - 1)));
     const uint32_t y_base = A.y0 + (t / A.strips) * (P * kLY) + (uint32_t)(lane >> 4);
-    if ((t % A.strips) * (kWaves * kLX) + (uint32_t)(wave * kLX) >= A.w) return;  // (wave-uniform) this wave's 16 columns lie beyond the frame
+    // (wave-uniform) false: this wave's 16 columns lie beyond the frame; it only keeps the workgroup's barriers company
+    const bool in_frame = (t % A.strips) * (kWaves * kLX) + (uint32_t)(wave * kLX) < A.w;
 
     float dx[P], dy[P], dz[P], best_t[P];
     int best_i[P];
@@ -708,7 +728,7 @@ __global__ __launch_bounds__(kWaves * 64) void render_cull_kernel(const RenderAr
     // ---- the cone of the tile's directions (a ray with a non-finite direction misses every exact test and needs no candidates) ----
     float ax, ay, az, sinT, cosT;
     const bool wide = !tile_cone<P>(dx, dy, dz, ax, ay, az, sinT, cosT);
-    {
+    if (in_frame) {
         int count = 0;
         auto walk = [&]() {
             const int padded = (count + B - 1) / B * B;
@@ -791,7 +811,7 @@ __global__ __launch_bounds__(kWaves * 64) void render_cull_kernel(const RenderAr
         }
         if (count > 0) walk();
     }
-    finish_tile<P, EMIT>(A, lane, inb, x_base, y_base, dx, dy, dz, best_t, best_i);
+    finish_tile<P, EMIT>(A, lane, inb, x_base, y_base, dx, dy, dz, best_t, best_i, EMIT ? s_agg : nullptr);
 }
 
 // Occlusion bits of every (live record, point light) pair of this iteration, semantics of the oracle's occluded().  A persistent grid
