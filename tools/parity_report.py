@@ -36,6 +36,8 @@ with capi.Context(0) as ctx:
     m = orc.default_camera(100, 100)
     g, gh = ctx.render_rows(m, 100, 100, 0, 100, 1, 0, want_hit_idx=True)
     compare("C1 vs the reference's result.png", g[..., :3], gold, gh, gh)
+    g, gh2 = ctx.render_rows(m, 100, 100, 0, 100, 1, capi.RT_CULL, want_hit_idx=True)
+    compare("C1 with RT_CULL vs the reference's result.png", g[..., :3], gold, gh2, gh)
     for cfg, step, flags, depth in (("C3", 8, 0, 1), ("C4", 48, 0, 1), ("C5", 24, 0, 1), ("C5", 60, 1, 1), ("C3", 24, 0, 2)):
         w, h, o, l = scenegen.config(cfg)
         m = orc.default_camera(w, h)
@@ -44,6 +46,9 @@ with capi.Context(0) as ctx:
         g, gh = ctx.render_rows(m, w, h, 0, h, depth, flags, want_hit_idx=True)
         r, rh = orc.render(o, l, m, w, h, row_step=step, depth=depth, flags=flags, want_hit_idx=True)
         compare(f"{cfg} {w}x{h} N={o.n} L={l.n} depth={depth} shadows={flags} (every {step}th row)", g[::step], r[::step], gh[::step], rh[::step])
+        gc, ghc = ctx.render_rows(m, w, h, 0, h, depth, flags | capi.RT_CULL, want_hit_idx=True)  # opt-in: primary rays through the cone hierarchy
+        compare(f"{cfg} depth={depth} shadows={flags} with RT_CULL vs the oracle (every {step}th row)", gc[::step], r[::step], ghc[::step], rh[::step])
+        compare(f"{cfg} depth={depth} shadows={flags} with RT_CULL vs the default launch (WHOLE frame)", gc, g, ghc, gh)
         print(cfg, flags, depth, "%.1f s" % (time.time() - t0), flush=True)
 
 lines += ["", "## Grazing-edge hit/miss differences", ""]
