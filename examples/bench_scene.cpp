@@ -33,7 +33,9 @@ int main(int argc, char** argv)
     }
     const char* name = argc > 1 ? argv[1] : "C3";
     const int frames = argc > 2 ? std::atoi(argv[2]) : 20;
-    const uint32_t flags = (argc > 3 && std::atoi(argv[3])) ? RT_SHADOWS : 0u;
+    // RT_FLAGS_EXTRA: further library flags, e.g. RT_FLAGS_EXTRA=8 = RT_CULL (same frame through the cone hierarchy: the hash must not change)
+    const uint32_t extra = std::getenv("RT_FLAGS_EXTRA") ? (uint32_t)std::strtoul(std::getenv("RT_FLAGS_EXTRA"), nullptr, 0) : 0u;
+    const uint32_t flags = ((argc > 3 && std::atoi(argv[3])) ? RT_SHADOWS : 0u) | extra;
     const uint32_t depth = argc > 4 ? (uint32_t)std::atoi(argv[4]) : 1u;
     SyntheticScene sc;
     if (!config_scene(name, sc) || frames < 1) {

@@ -69,9 +69,11 @@ impl GpuContext {
     }
 
     /// Writes `h` rows of `w` RGB8 pixels (the layout of `Framebuffer.pixels`, display.rs:16-20) into `out`.
-    pub fn render_rgb8(&mut self, m: &[f32; 16], w: u32, h: u32, depth: u32, out: &mut [u8]) -> anyhow::Result<()> {
+    /// `flags`: 0 = the reference's per-pixel walk of the element list; `RT_CULL` = same bytes through the cone hierarchy (opt-in);
+    /// `RT_SHADOWS` = the occlusion extension.
+    pub fn render_rgb8(&mut self, m: &[f32; 16], w: u32, h: u32, depth: u32, flags: u32, out: &mut [u8]) -> anyhow::Result<()> {
         anyhow::ensure!(out.len() == 3 * (w as usize) * (h as usize), "pixel store has the wrong size");
-        check(unsafe { rt_render(self.raw, m.as_ptr(), w, h, depth, RT_OUT_RGB8, out.as_mut_ptr()) }, self.raw)
+        check(unsafe { rt_render(self.raw, m.as_ptr(), w, h, depth, flags | RT_OUT_RGB8, out.as_mut_ptr()) }, self.raw)
     }
 }
 
@@ -112,6 +114,14 @@ where
     where
         E: Send + Sync,
     {
+        self.render_flags(devices, depth, 0)
+    }
+
+    /// Same with library flags: `RT_CULL` (same image, primary rays through the cone hierarchy) and / or `RT_SHADOWS` (extension).
+    pub fn render_flags(&mut self, devices: &[i32], depth: usize, flags: u32) -> anyhow::Result<()>
+    where
+        E: Send + Sync,
+    {
         anyhow::ensure!(depth >= 1, "depth must be >= 1"); // the original computes `depth - 1` on usize (renderer.rs:36)
         anyhow::ensure!(depth <= u32::MAX as usize, "depth too large");
         let scene = match flatten_scene(self.elements.borrow(), self.lights.borrow()) {
@@ -130,7 +140,7 @@ where
         }
         let (w, h) = (self.frame.width(), self.frame.height());
         // RT_OUT_RGB8 is Framebuffer.pixels' own layout (3 B/pixel, row 0 = top): no conversion pass
-        ctx.render_rgb8(&m, w, h, depth as u32, self.frame.pixels_mut())?;
+        ctx.render_rgb8(&m, w, h, depth as u32, flags, self.frame.pixels_mut())?;
         drop(ctx);
         self.frame.display()?; // renderer.rs:79, unchanged
         self.frame.clear(); // renderer.rs:80, unchanged

@@ -763,9 +763,10 @@ def test_native_bench_harness(tmp_path, gpu_ctx):
     import subprocess
     exe = os.path.abspath(os.path.join(os.path.dirname(GOLDEN), "..", "examples", "bench_scene"))
     assert os.path.exists(exe), "build it first: make -C examples (done by __graft_entry__.build())"
-    for name, shadows in (("C3", 0), ("C5", 1)):
+    for name, shadows, extra in (("C3", 0, 0), ("C5", 1, 0), ("C3", 0, capi.RT_CULL)):
         dump = tmp_path / f"{name}.rgba"
-        r = subprocess.run([exe, name, "2", str(shadows), "1", str(dump)], capture_output=True, text=True, timeout=300)
+        r = subprocess.run([exe, name, "2", str(shadows), "1", str(dump)], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, RT_FLAGS_EXTRA=str(extra)))
         assert r.returncode == 0, r.stderr
         assert "primary rays/s" in r.stdout
         w, h, objs, lights = scenegen.config(name)
