@@ -77,4 +77,5 @@ extern "C" {
     pub fn rt_debug_prepare_spheres(objects: *const rt_objects, filt: *mut f32, cls: *mut u8) -> i32;
     pub fn rt_debug_prepare_shadow_cull(objects: *const rt_objects, lights: *const rt_lights, light: i32, order: *mut i32, lfilt: *mut f32,
                                         cl_a: *mut f32, cl_b: *mut f32, always: *mut i32, n_always: *mut i32) -> i32;
+    pub fn rt_debug_prepare_primary_cull(objects: *const rt_objects, order: *mut i32, pfilt: *mut f32, cl_a: *mut f32, cl_b: *mut f32) -> i32;
 }
