@@ -196,6 +196,22 @@ __device__ __forceinline__ void primary_dir(const RenderArgs& A, uint32_t x, uin
     unit3(dx, dy, dz);
 }
 
+// The same, also returning |pos| as unit() computes it (vec3.rs:195-197): the culled kernel bounds the rounding error of a direction with it
+__device__ __forceinline__ void primary_dir_norm(const RenderArgs& A, uint32_t x, uint32_t y, float& dx, float& dy, float& dz, float& n)
+{
+    const float v0 = 2.0f * ((float)x / (float)A.w) - 1.0f;
+    const float v1 = 2.0f * ((float)y / (float)A.h) - 1.0f;
+    const float v2 = 2.0f * (1.0f / 1.0f) - 1.0f;
+    const float v3 = v2;
+    dx = dot4_ref(A.m + 0, v0, v1, v2, v3);
+    dy = dot4_ref(A.m + 4, v0, v1, v2, v3);
+    dz = dot4_ref(A.m + 8, v0, v1, v2, v3);
+    n = sqrtf(dot3_ref(dx, dy, dz, dx, dy, dz));
+    dx = dx / n;
+    dy = dy / n;
+    dz = dz / n;
+}
+
 __device__ __forceinline__ void store_pixel(const RenderArgs& A, size_t pix, float cr, float cg, float cb)
 {
     const uint32_t r8 = quantise(cr), g8 = quantise(cg), b8 = quantise(cb);
@@ -623,20 +639,27 @@ __device__ __forceinline__ bool wave_cone(uint32_t mask, const float (&dx)[P], c
 }
 
 // The cone of a TILE of primary rays without any cross-lane reduction: pos = M v is affine in the pixel coordinates (display.rs:98-100), so
-// the directions of a wave's pixel rectangle lie in the convex cone spanned by its four CORNER directions, and for every x of that cone
-// cos(angle(a, x)) >= the smallest cos(angle(a, corner)) as long as all four are positive.  The corners are held by lanes 0 and 15 (first
-// row, ray slot 0) and 48 and 63 (last row, ray slot P - 1) — clamped pixels at the frame's edge included — and are read with
-// v_readlane; everything after that is wave-uniform.  sinT carries 4e-6 of absolute slack: the f32 roundings of v, pos and unit()
-// move a direction by a few 1e-7 off the affine model.  Returns false ("no cone": the caller keeps every sphere) if a corner is not
-// finite or the corners do not fit within 60 degrees of their normalised sum.
+// in exact arithmetic the directions of a wave's pixel rectangle lie in the convex cone spanned by its four CORNER directions, and for
+// every x of that cone cos(angle(a, x)) >= the smallest cos(angle(a, corner)) as long as all four are positive.  The corners are held
+// by lanes 0 and 15 (first row, ray slot 0) and 48 and 63 (last row, ray slot P - 1) — clamped pixels at the frame's edge included —
+// and are read with v_readlane; everything after that is wave-uniform.
+// Rounding: the f32 evaluation of display.rs:98-100 puts every pos within  e = 6u (S0^2 + S1^2 + S2^2)^(1/2),  S_r = sum |m_r.|, of the
+// affine model (v: 3u absolute; the two products 4u |m_r0|, 4u |m_r1|; the three sums u each of at most S_r; u = 2^-24) — that is NOT small
+// against |pos| when the rows of a caller's matrix cancel — and a point of the parallelogram is at least half as far from the origin
+// as the nearest corner (its corners lie within 60 degrees of the axis), so a computed direction is within  delta = 2 e / min |pos_corner|
+// of the model's, a corner's own included.  `err` = 8u |S| comes in from the kernel, the corner norms from primary_dir_norm;
+// sinT carries 3 x 2.5 err / min|pos| + 4e-6 (normalisation, cross product) of slack.  Returns false ("no cone": the caller keeps every
+// sphere) if a corner is not finite, the corners do not fit within 60 degrees of their normalised sum, or delta is not small.
 template <int P>
-__device__ __forceinline__ bool tile_cone(const float (&dx)[P], const float (&dy)[P], const float (&dz)[P], float& ax, float& ay, float& az,
-                                          float& sinT, float& cosT)
+__device__ __forceinline__ bool tile_cone(const float (&dx)[P], const float (&dy)[P], const float (&dz)[P], const float (&nrm)[P], float err,
+                                          float& ax, float& ay, float& az, float& sinT, float& cosT)
 {
     auto corner = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
     const float gx[4] = {corner(dx[0], 0), corner(dx[0], 15), corner(dx[P - 1], 48), corner(dx[P - 1], 63)};
     const float gy[4] = {corner(dy[0], 0), corner(dy[0], 15), corner(dy[P - 1], 48), corner(dy[P - 1], 63)};
     const float gz[4] = {corner(dz[0], 0), corner(dz[0], 15), corner(dz[P - 1], 48), corner(dz[P - 1], 63)};
+    const float nmin = __builtin_fminf(__builtin_fminf(corner(nrm[0], 0), corner(nrm[0], 15)), __builtin_fminf(corner(nrm[P - 1], 48), corner(nrm[P - 1], 63)));
+    const float delta = 2.5f * err / nmin;
     ax = (gx[0] + gx[1]) + (gx[2] + gx[3]);
     ay = (gy[0] + gy[1]) + (gy[2] + gy[3]);
     az = (gz[0] + gz[1]) + (gz[2] + gz[3]);
@@ -654,9 +677,9 @@ __device__ __forceinline__ bool tile_cone(const float (&dx)[P], const float (&dy
         cmin = __builtin_fminf(cmin, c);
         smax = __builtin_fmaxf(smax, sqrtf(kx * kx + ky * ky + kz * kz));
     }
-    sinT = smax * (1.0f + 1.0e-6f) + 4.0e-6f;
+    sinT = smax * (1.0f + 1.0e-6f) + (4.0e-6f + 3.0f * delta);
     cosT = sqrtf(__builtin_fmaxf(0.0f, 1.0f - sinT * sinT)) * (1.0f - 1.0e-6f);
-    return finite && an > 0.0f && an < INFINITY && cmin > 0.5f && cmin <= 2.0f;
+    return finite && an > 0.0f && an < INFINITY && cmin > 0.5f && cmin <= 2.0f && delta < 0.05f;
 }
 
 // ---- RT_CULL: the primary rays through the cone hierarchy ------------------------------------------------------------------------------
@@ -691,7 +714,7 @@ __global__ __launch_bounds__(kWaves * 64) void render_cull_kernel(const RenderAr
     // (wave-uniform) false: this wave's 16 columns lie beyond the frame; it only keeps the workgroup's barriers company
     const bool in_frame = (t % A.strips) * (kWaves * kLX) + (uint32_t)(wave * kLX) < A.w;
 
-    float dx[P], dy[P], dz[P], best_t[P];
+    float dx[P], dy[P], dz[P], nrm[P], best_t[P];
     int best_i[P];
     uint32_t inb = 0;
 #pragma unroll
@@ -701,7 +724,7 @@ __global__ __launch_bounds__(kWaves * 64) void render_cull_kernel(const RenderAr
         if (x < A.w && y < A.y1) inb |= 1u << p;
         x = min(x, A.w - 1u);
         y = min(y, A.y1 - 1u);
-        primary_dir(A, x, y, dx[p], dy[p], dz[p]);
+        primary_dir_norm(A, x, y, dx[p], dy[p], dz[p], nrm[p]);
         best_t[p] = 0.0f;
         best_i[p] = -1;
     }
@@ -727,7 +750,14 @@ __global__ __launch_bounds__(kWaves * 64) void render_cull_kernel(const RenderAr
     }
     // ---- the cone of the tile's directions (a ray with a non-finite direction misses every exact test and needs no candidates) ----
     float ax, ay, az, sinT, cosT;
-    const bool wide = !tile_cone<P>(dx, dy, dz, ax, ay, az, sinT, cosT);
+    float err;  // 8u |S|: bound (with margin) of the rounding error of a computed pos, see tile_cone
+    {
+        const float s0 = (__builtin_fabsf(A.m[0]) + __builtin_fabsf(A.m[1])) + (__builtin_fabsf(A.m[2]) + __builtin_fabsf(A.m[3]));
+        const float s1 = (__builtin_fabsf(A.m[4]) + __builtin_fabsf(A.m[5])) + (__builtin_fabsf(A.m[6]) + __builtin_fabsf(A.m[7]));
+        const float s2 = (__builtin_fabsf(A.m[8]) + __builtin_fabsf(A.m[9])) + (__builtin_fabsf(A.m[10]) + __builtin_fabsf(A.m[11]));
+        err = 4.76837158203125e-07f * sqrtf(s0 * s0 + s1 * s1 + s2 * s2);
+    }
+    const bool wide = !tile_cone<P>(dx, dy, dz, nrm, err, ax, ay, az, sinT, cosT);
     if (in_frame) {
         int count = 0;
         auto walk = [&]() {

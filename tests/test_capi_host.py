@@ -212,7 +212,7 @@ def test_shadow_hierarchy_is_conservative(oracle, seed):
 @pytest.mark.parametrize("seed", [1, 2])
 def test_primary_cull_hierarchy_is_conservative(oracle, seed):
     """RT_CULL (scene_prep.cpp: prepare_primary_cull; render_kernels.hip: tile_cone / render_cull_kernel), emulated in f32 on the CPU for
-    16 x 16 pixel tiles of several cameras: (1) every direction of a tile lies inside the cone built from its four corner directions,
+    16 x 16 pixel tiles of several cameras: (1) every direction of a tile lies inside the cone built from its four corner directions (widened by the rounding bound delta; one camera matrix has rows that cancel),
     (2) every candidate of the per-pixel filter passes the member cone test and its cluster passes the cluster cone test — so the votes
     never drop a sphere the walk over the whole list would have tested — and (3) the order lists exactly the filterable spheres."""
     f32 = np.float32
@@ -234,19 +234,37 @@ def test_primary_cull_hierarchy_is_conservative(oracle, seed):
     assert (np.linalg.norm(pf[entry, :3].astype(np.float64), axis=1) > 4).any(), "the always-open member branch is exercised"
     P1 = f32(1.0) - f32(3.814697265625e-06)
     rng = np.random.default_rng(40 + seed)
-    cams = [(1920, 1080, None), (3840, 2160, None), (100, 100, None), (333, 77, None)]
+    cams = [(1920, 1080, None, None), (3840, 2160, None, None), (100, 100, None, None), (333, 77, None, None)]
     g = (rng.standard_normal(16) * 0.7).astype(f32); g[10] -= f32(1.5)
-    cams.append((640, 360, g))
-    cand_total = listed = tiles = wides = 0
-    for (w, h, m) in cams:
+    cams.append((640, 360, g, None))
+    # a matrix whose rows CANCEL: pos = default camera + K (v0 - 0.31), evaluated as (m_r0 v0 + ..) + (.. + m_r3) with |m_r0|, |m_r3| ~ 1e3:
+    # every computed pos is off the affine model by ~1e-4 although |pos| ~ 1 near v0 = 0.31 — what tile_cone's delta term is for
+    adv = oracle.default_camera(1920, 1080).copy()
+    for r_, k_ in enumerate((800.0, -600.0, 500.0)):
+        adv[4 * r_ + 0] += f32(k_)
+        adv[4 * r_ + 3] -= f32(k_) * f32(0.31)
+    cams.append((1920, 1080, adv, int((0.31 + 1) / 2 * 1920)))
+    cand_total = listed = tiles = wides = outside_without_delta = 0
+    u = 2.0 ** -24
+    for (w, h, m, x_near) in cams:
         m = oracle.default_camera(w, h) if m is None else m
+        S = np.abs(np.asarray(m, f32)[:12].reshape(3, 4)).astype(f32)
+        Sr = ((S[:, 0] + S[:, 1]).astype(f32) + (S[:, 2] + S[:, 3]).astype(f32)).astype(f32)
+        err = f32(f32(4.76837158203125e-07) * np.sqrt((Sr * Sr).sum(dtype=f32), dtype=f32))
         for _ in range(10):
             x0 = int(rng.integers(0, (w + 15) // 16)) * 16
+            if x_near is not None:
+                x0 = (x_near + int(rng.integers(-3, 4))) // 16 * 16
             y0 = int(rng.integers(0, (h + 15) // 16)) * 16
             xs = np.minimum(x0 + np.arange(16), w - 1)   # the kernel clamps pixels beyond the frame's edge
             ys = np.minimum(y0 + np.arange(16), h - 1)
-            dirs = np.array([[oracle.unit3(oracle.pixel_position(m, int(x), int(y), w, h)) for x in xs] for y in ys], f32)  # [row, col, 3]
+            pos = np.array([[oracle.pixel_position(m, int(x), int(y), w, h) for x in xs] for y in ys], f32)  # [row, col, 3]
+            nrm = np.sqrt(((pos[..., 0] * pos[..., 0] + pos[..., 1] * pos[..., 1]).astype(f32) + pos[..., 2] * pos[..., 2]).astype(f32), dtype=f32)
+            dirs = (pos / nrm[..., None]).astype(f32)
+            assert np.array_equal(dirs[3, 5], oracle.unit3(pos[3, 5]))
             corners = np.stack([dirs[0, 0], dirs[0, 15], dirs[15, 0], dirs[15, 15]])
+            nmin = f32(min(nrm[0, 0], nrm[0, 15], nrm[15, 0], nrm[15, 15]))
+            delta = f32(f32(2.5) * err / nmin)
             # tile_cone as the kernel evaluates it
             a = ((corners[0] + corners[1]).astype(f32) + (corners[2] + corners[3]).astype(f32)).astype(f32)
             an = np.sqrt((a * a).sum(dtype=f32), dtype=f32)
@@ -254,13 +272,14 @@ def test_primary_cull_hierarchy_is_conservative(oracle, seed):
             c = (corners * a).sum(1, dtype=f32)
             cr = np.cross(a.astype(np.float64), corners.astype(np.float64)).astype(f32)
             smax = f32(np.sqrt((cr * cr).sum(1, dtype=f32), dtype=f32).max())
-            wide = not (np.isfinite(corners).all() and an > 0 and np.isfinite(an) and c.min() > 0.5)
-            sinT = f32(smax * f32(1.0 + 1.0e-6) + f32(4.0e-6))
+            wide = not (np.isfinite(corners).all() and an > 0 and np.isfinite(an) and c.min() > 0.5 and delta < 0.05)
+            sinT = f32(smax * f32(1.0 + 1.0e-6) + f32(f32(4.0e-6) + f32(3.0) * delta))
             cosT = f32(np.sqrt(max(f32(0), f32(1.0) - sinT * sinT), dtype=f32) * f32(1.0 - 1.0e-6))
             flat = dirs.reshape(-1, 3)
             if not wide:  # (1) in float64: the sine of the angle between the axis and every direction of the tile
                 s64 = np.linalg.norm(np.cross(a.astype(np.float64), flat.astype(np.float64)), axis=1) / np.linalg.norm(flat.astype(np.float64), axis=1)
-                assert (s64 <= float(smax) * (1 + 1e-6) + 2.0e-6).all(), "a direction of the tile lies outside the corner cone"
+                assert (s64 <= float(smax) * (1 + 1e-6) + 2.0e-6 + 1.5 * float(delta)).all(), "a direction of the tile lies outside the corner cone"
+                outside_without_delta += int((s64 > float(smax) * (1 + 1e-6) + 4.0e-6).sum())
             # (2) per-pixel filter candidates over all positions, member and cluster votes as the kernel evaluates them
             fv = _fma32(flat[:, 0:1], pf[None, :, 0], _fma32(flat[:, 1:2], pf[None, :, 1], _fma32(flat[:, 2:3], pf[None, :, 2], f32(-1.0))))
             cand = (fv >= 0) & entry[None, :]
@@ -270,15 +289,18 @@ def test_primary_cull_hierarchy_is_conservative(oracle, seed):
             cdot = _fma32(a[0], cla[:, 0], _fma32(a[1], cla[:, 1], f32(a[2] * cla[:, 2])))
             crhs = _fma32(cosT, clb[:, 0], -(sinT * clb[:, 1]).astype(f32))
             cdir = wide | (cdot >= crhs - f32(4.0e-6))
-            _, pos = np.nonzero(cand)
-            cand_total += len(pos)
-            assert mpass[pos].all(), "a filter candidate failed the member cone test"
-            assert cdir[pos // 16].all(), "the cluster of a filter candidate failed the cluster cone test"
-            listed += int((mpass & np.repeat(cdir, 16)).sum())
+            _, pos_ = np.nonzero(cand)
+            cand_total += len(pos_)
+            assert mpass[pos_].all(), "a filter candidate failed the member cone test"
+            assert cdir[pos_ // 16].all(), "the cluster of a filter candidate failed the cluster cone test"
+            listed += 0 if wide else int((mpass & np.repeat(cdir, 16)).sum())
             tiles += 1
             wides += int(wide)
+    # (the delta term is a proof device: even with the cancelling matrix no direction was seen outside the PLAIN corner cone — a
+    # pixel-dependent rounding error is at most ~1e-3 of the pixel spacing, far less than a tile's extent — so this stays an observation)
+    print("directions outside the corner cone without the delta term:", outside_without_delta)
     assert cand_total > 300 and wides < tiles // 4
-    assert listed / tiles < 0.1 * allo.n, "the hierarchy is a useful filter"
+    assert listed / (tiles - wides) < 0.1 * allo.n, "the hierarchy is a useful filter"
 
 
 def test_scenegen_is_deterministic_and_pinned():

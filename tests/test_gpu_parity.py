@@ -524,8 +524,31 @@ def test_cull_default_scene_edges_and_bands(gpu_ctx, oracle):
                 band, bhit = gpu_ctx.render_rows(m, w, h, y0, y1, 1, capi.RT_CULL | capi.RT_OUT_RGB8, want_hit_idx=True)
                 _assert_same(band, ref[y0:y1, :, :3], f"RT_CULL band {y0}:{y1} of {w}x{h}")
                 assert np.array_equal(bhit, ref_hit[y0:y1])
-    # camera inside / on / next to spheres, duplicates, a sphere behind the camera, a huge far one; two planes
+    # camera matrices that stress tile_cone: rows that cancel (large x-slope against a large constant), a 3000 : 1 pixel aspect, a
+    # tiny and a huge field of view, a scale of 1e-6 and of 1e6 on the whole matrix
     f = np.float32
+    w, h = 640, 360
+    o, li = scenegen.generate(w, h, 500, 3, seed=21)
+    gpu_ctx.scene_upload(o, li)
+    base = _cam(oracle, w, h)
+    mats = []
+    adv = base.copy()
+    for r_, k_ in enumerate((80.0, -60.0, 50.0)):
+        adv[4 * r_ + 0] += f(k_)
+        adv[4 * r_ + 3] -= f(k_) * f(0.31)
+    mats.append(adv)
+    an = base.copy(); an[0] *= f(3000.0); mats.append(an)
+    an = base.copy(); an[5] *= f(3000.0); mats.append(an)
+    mats.append(oracle.camera_transform(f(0.02), f(0.01), f(1000.0), f(w) / f(h)))
+    mats.append(oracle.camera_transform(f(3.1), f(0.01), f(1000.0), f(w) / f(h)))
+    mats.append((base * f(1e-6)).astype(f))
+    mats.append((base * f(1e6)).astype(f))
+    for k, m in enumerate(mats):
+        ref, ref_hit = oracle.render(o, li, m, w, h, want_hit_idx=True)
+        gpu, hit = gpu_ctx.render_rows(m, w, h, 0, h, 1, capi.RT_CULL, want_hit_idx=True)
+        _assert_same(gpu, ref, f"RT_CULL camera matrix {k}")
+        assert np.array_equal(hit, ref_hit), f"RT_CULL camera matrix {k}: hit plane"
+    # camera inside / on / next to spheres, duplicates, a sphere behind the camera, a huge far one; two planes
     c = np.array([[0, 0, 0, 3.0], [0, 0, -1, 1.0], [0.2, 0.1, -1, 0.99999], [0.5, 0.5, 4, 1.0], [0.1, 0.1, -3, 1e-4], [0, 0, -500, 400.0],
                   [1, 0.5, -4, 0.7], [1, 0.5, -4, 0.7], [-2, -1, -6, 1.1], [3, 2, -5, 6.16]], f)
     one = np.ones(len(c), f)
