@@ -295,6 +295,23 @@ __device__ __forceinline__ void finish_tile(const RenderArgs& A, int lane, uint3
             }
             off += (uint32_t)__builtin_popcountll(hitmask[p]);
         }
+        if (s_agg && A.sort_bins) {
+            // the histogram of the first record sort (sort_records_kernel<false>), taken here while the elements are in registers: one
+            // atomic (no return value) per distinct element of a ray slot; launch_render zeroes the bins before this kernel and skips
+            // the histogram launch of iteration 0
+#pragma unroll
+            for (int p = 0; p < P; ++p) {
+                const bool hit = ((inb >> p) & 1u) && best_i[p] >= 0;
+                const int key = hit ? A.rank[best_i[p]] : -1;
+                uint64_t todo = hitmask[p];
+                while (todo) {
+                    const int k0 = __builtin_amdgcn_readlane(key, __builtin_ctzll(todo));
+                    const uint64_t same = __builtin_amdgcn_ballot_w64(key == k0);
+                    if (lane == 0) atomicAdd(A.sort_bins + k0, (uint32_t)__builtin_popcountll(same));
+                    todo &= ~same;
+                }
+            }
+        }
     }
 }
 
@@ -1636,7 +1653,9 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream, PhaseEvents
     if (!args.rec_count || !args.rec_pix || !args.rec_idx || !args.rec_t || args.rec_cap < npix) return hipErrorInvalidValue;
     if ((args.depth > 1u && !args.rec_state) || (shadows && !args.rec_occ)) return hipErrorInvalidValue;
     if ((shadows || args.depth > 1u) && (!args.rec_perm || !args.rec_hit || !args.sort_bins)) return hipErrorInvalidValue;
-    hipError_t e = clear_words(nullptr, 0, 0, 0, args.rec_count, 1, stream);
+    // RT_CULL: the emit kernel also takes the histogram of the first record sort (finish_tile), so its bins are cleared up front
+    const bool emit_hist = cull && args.sort_bins != nullptr;
+    hipError_t e = emit_hist ? clear_words(args.sort_bins, (size_t)args.n + 1, 0, 1, args.rec_count, 1, stream) : clear_words(nullptr, 0, 0, 0, args.rec_count, 1, stream);
     if (e != hipSuccess) return e;
     if (phases && (e = hipEventRecord(phases->ev[0], stream)) != hipSuccess) return e;
     if ((e = cull ? launch_primary_cull<true>(args, stream) : launch_primary<true>(args, stream)) != hipSuccess) return e;
@@ -1655,9 +1674,10 @@ hipError_t launch_render(const RenderArgs& args, hipStream_t stream, PhaseEvents
         a.sorted = (shadows || tracing) ? 1u : 0u;
         if (a.sorted) {
             // spatial sort of the live records (rec_idx of this iteration) -> rec_perm, their hit points -> rec_hit, live count -> rec_count[1]
-            if ((e = clear_words(a.sort_bins, (size_t)a.n + 1, 0, 1, nullptr, 0, stream)) != hipSuccess) return e;
+            const bool have_hist = it == 0 && emit_hist;  // the culled emit kernel took the histogram of iteration 0 itself
+            if (!have_hist && (e = clear_words(a.sort_bins, (size_t)a.n + 1, 0, 1, nullptr, 0, stream)) != hipSuccess) return e;
             const uint32_t sort_wgs = (uint32_t)(npix + 255) / 256 < 2048u ? (uint32_t)(npix + 255) / 256 : 2048u;
-            hipLaunchKernelGGL((sort_records_kernel<false>), dim3(sort_wgs), dim3(256), 0, stream, a);
+            if (!have_hist) hipLaunchKernelGGL((sort_records_kernel<false>), dim3(sort_wgs), dim3(256), 0, stream, a);
             hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(256), 0, stream, a);
             hipLaunchKernelGGL((sort_records_kernel<true>), dim3(sort_wgs), dim3(256), 0, stream, a);
             if ((e = hipGetLastError()) != hipSuccess) return e;
